@@ -1,0 +1,200 @@
+/*
+ * libmtc — C ABI of the MI355X-native Matryoshka-transcoder hot path.
+ *
+ * The reference (a1842806/matryoshka_transcoder) is pure Python on PyTorch and has no FFI
+ * layer; its boundary is the Python surface of `MatryoshkaTranscoder` (src/models/sae.py:73-406)
+ * and the step body of `train_transcoder` (src/training/training.py:172-183).  Every entry
+ * point below names the reference lines it replaces.  The Python package
+ * `matryoshka_transcoder_amd` binds these with ctypes.
+ *
+ * Conventions
+ *   - plain C types only; every pointer is a DEVICE pointer unless the name ends in `_host`;
+ *   - the caller owns every buffer (inputs, outputs, workspace); the library allocates nothing
+ *     and keeps no state besides a thread-local error string;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*) and never
+ *     synchronises; scalars that depend on device results stay on the device;
+ *   - return value 0 = success, negative = error (mtc_last_error() has the text);
+ *   - matrices are row-major and contiguous.  The encoder weight is passed FEATURE-MAJOR:
+ *     `W_encT[D][A_s]`, i.e. the transpose of the reference's `W_enc[A_s][D]` (the Python layer
+ *     keeps the `W_enc` parameter as a transposed view of this storage, so state_dict shapes
+ *     and values are the reference's);
+ *   - `dtype` is the model dtype of parameters / activations: MTC_BF16 or MTC_F32.
+ */
+#ifndef MTC_H
+#define MTC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MTC_VERSION 1
+#define MTC_MAX_PREFIX 16
+
+enum { MTC_F32 = 0, MTC_BF16 = 1 };
+
+/* Problem description shared by all ops. */
+typedef struct mtc_desc {
+    int32_t B;                       /* batch rows (tokens)                                    */
+    int32_t A_s;                     /* source activation width  (multiple of 8)               */
+    int32_t A_t;                     /* target activation width  (multiple of 8, <= 8192)      */
+    int32_t D;                       /* dictionary size held by this process (local shard)     */
+    int32_t G;                       /* number of nested prefix groups (<= MTC_MAX_PREFIX)     */
+    int32_t prefix[MTC_MAX_PREFIX];  /* cumulative prefix sizes in LOCAL feature coordinates    */
+    int32_t dtype;                   /* MTC_F32 | MTC_BF16                                     */
+    int32_t unit_norm;               /* cfg["input_unit_norm"]                                 */
+} mtc_desc;
+
+/* Device-resident state of the global select (one per call chain; 64 bytes). */
+typedef struct mtc_select_state {
+    uint32_t key_prefix;   /* bits of tau fixed so far (float32 bit pattern, upper bits)      */
+    uint32_t k_rem;        /* how many entries still to take inside the current bin           */
+    uint32_t all_pos;      /* 1: fewer than k positives exist -> every positive is selected   */
+    uint32_t n_gt;         /* entries strictly greater than tau                               */
+    uint32_t tau_bits;     /* float32 bit pattern of tau (valid after the last level)         */
+    uint32_t n_tie_take;   /* entries equal to tau that are selected                          */
+    uint32_t min_sel_bits; /* float32 bits of the smallest selected value (atomicMin)         */
+    uint32_t nnz;          /* number of selected entries                                      */
+    uint32_t pad[8];
+} mtc_select_state;
+
+const char* mtc_last_error(void);
+int mtc_version(void);
+
+/* a2  preprocess_input (sae.py:139-147): x <- (x - mean_row) / (std_row_unbiased + 1e-5), each step
+ * rounded to the model dtype as the reference's eager ops do.  mean/std: [B] in the model dtype. */
+int mtc_row_normalize(const mtc_desc* d, const void* x, void* x_norm, void* mean, void* std,
+                      void* stream);
+
+/* a3  compute_activations, dense part (sae.py:173-174): acts = relu(round(round(x.W_enc) + b_enc)),
+ * acts [B][D] in the model dtype.  bf16: MFMA 16x16x32, fp32 accumulate; fp32: f32 MFMA. */
+int mtc_encode_fwd(const mtc_desc* d, const void* x, const void* W_encT, const void* b_enc,
+                   void* acts, void* stream);
+
+/* a3  global batch-TopK (sae.py:176-187) as an exact k-th-largest threshold select over the
+ * B*D activations; a5 threshold EMA input (sae.py:358-360) falls out as min_sel_bits.
+ * Phases are separate entry points so a feature-sharded caller can all-reduce `hist` between
+ * them; mtc_select_global_topk() chains them for one GPU.
+ *   level 0: float bits [30:19]   level 1: [18:7] (bf16: [18:16])   level 2: [6:0] (fp32 only)
+ * hist: 4096 uint32 (caller zeroes it; mtc_select_hist adds into it). */
+int mtc_select_levels(const mtc_desc* d);
+int mtc_select_init(mtc_select_state* st, uint32_t k_total, void* stream);
+int mtc_select_hist(const mtc_desc* d, const void* acts, int level, const mtc_select_state* st,
+                    uint32_t* hist, void* stream);
+int mtc_select_scan(const mtc_desc* d, int level, const uint32_t* hist, mtc_select_state* st,
+                    void* stream);
+/* per-row counts of values > tau and == tau (or, threshold mode, > *threshold: sae.py:189-191) */
+int mtc_select_count(const mtc_desc* d, const void* acts, const mtc_select_state* st,
+                     const void* threshold /* NULL in TopK mode; model-dtype scalar otherwise */,
+                     uint32_t* row_gt, uint32_t* row_eq, void* stream);
+/* row_ptr[B+1] and per-row tie quota from the counts.  tie_before (optional, [B]) = ties that
+ * precede this shard's row b in the global (row, shard) order; NULL = exclusive scan of row_eq. */
+int mtc_select_offsets(const mtc_desc* d, const uint32_t* row_gt, const uint32_t* row_eq,
+                       const uint32_t* tie_before, mtc_select_state* st, int32_t* row_ptr,
+                       uint32_t* tie_take, void* stream);
+/* ordered compaction: col_idx ascending inside each row; vals in the model dtype */
+int mtc_select_fill(const mtc_desc* d, const void* acts, const mtc_select_state* st,
+                    const void* threshold, const int32_t* row_ptr, const uint32_t* tie_take,
+                    int32_t* col_idx, void* vals, void* stream);
+size_t mtc_select_workspace_bytes(const mtc_desc* d);
+int mtc_select_global_topk(const mtc_desc* d, const void* acts, uint32_t k_total,
+                           const void* threshold /* NULL = TopK mode */, void* workspace,
+                           size_t workspace_bytes, mtc_select_state* st, int32_t* row_ptr,
+                           int32_t* col_idx, void* vals, void* stream);
+
+/* a5  update_threshold (sae.py:349-361): threshold <- (1-lr)*threshold + lr*min_selected, evaluated
+ * in the buffer dtype, skipped when nothing was selected. */
+int mtc_threshold_ema(const mtc_desc* d, const mtc_select_state* st, void* threshold, float lr,
+                      void* stream);
+
+/* a6/a8/a10  nested prefix decode (sae.py:217-230) in sparse form, one wavefront per batch row:
+ * x_hat_i = sum_{j < P_i} a_bj W_dec[j] + b_dec accumulated incrementally per prefix group,
+ * de-normalised (sae.py:149-153) and rounded to the model dtype; fused per-row partials of the
+ * per-prefix squared error (losses sae.py:236, FVU config.py:222-232) and of sum(x_t), sum(x_t^2).
+ *   x_hat     [B][A_t] model dtype (last prefix)          row_stats [G+4][B] float:
+ *   g         [B][A_t] float, = 2/(B*A_t) * (x_hat-x_t) * std_row    rows 0..G-1  SSE of prefix i
+ *             (NULL = forward only)                                  row G sum x_t, G+1 sum x_t^2,
+ *   recons    optional [G][B][A_t] model dtype (every prefix)        row G+2 sum |a|, G+3 unused */
+int mtc_decode_fwd(const mtc_desc* d, const int32_t* row_ptr, const int32_t* col_idx,
+                   const void* vals, const void* W_dec, const void* b_dec, const void* x_target,
+                   const void* mean, const void* std, void* x_hat, float* g, float* row_stats,
+                   void* recons, float* d_vals /* NULL, or [nnz]: fused a11 sweep, see
+                   mtc_decode_bwd_vals */, float l1_term, void* stream);
+
+/* feature-sharded variant: partial (bias-free) cumulative reconstructions in fp32,
+ * partial[G][B][A_t]; after the all-reduce mtc_decode_finish() does the epilogue above. */
+int mtc_decode_partial(const mtc_desc* d, const int32_t* row_ptr, const int32_t* col_idx,
+                       const void* vals, const void* W_dec, float* partial,
+                       float* abs_rows /* [B] sum |a| of the local entries, or NULL */, void* stream);
+int mtc_decode_finish(const mtc_desc* d, const float* partial, const void* b_dec,
+                      const void* x_target, const void* mean, const void* std, void* x_hat,
+                      float* g, float* row_stats, void* recons, void* stream);
+
+/* a8/a10/a14  scalar epilogue: reduces row_stats (and the optional aux partials) to the
+ * reference's output scalars without leaving the device.
+ *   scalars (float[16]): 0 l2  1 l1  2 l0  3 l1_norm  4 aux  5 loss  6 fvu  7 fvu_min  8 fvu_max
+ *                        9 fvu_mean  10 var(x_t)  11 nnz  12..15 reserved
+ * l2/l1/l1_norm are rounded to the model dtype (sae.py:236-239), the rest are fp32.
+ * n_rows_total/n_feat_total: global B and D (they differ from d->D when sharded). */
+int mtc_reduce_scalars(const mtc_desc* d, const float* row_stats, const float* aux_rows /*[B] or NULL*/,
+                       const mtc_select_state* st,
+                       const float* nnz_abs_override /* NULL, or device float[2] {global nnz, global
+                       sum |a|} when the selection is sharded */,
+                       int32_t n_feat_total, float l1_coeff, float aux_penalty, float* scalars,
+                       void* stream);
+
+/* a11  d a_bj = g_b . W_dec[j] (+ l1_coeff/(B*D)) for every selected entry, CSR order. */
+int mtc_decode_bwd_vals(const mtc_desc* d, const int32_t* row_ptr, const int32_t* col_idx,
+                        const void* W_dec, const float* g, float l1_term, float* d_vals,
+                        void* stream);
+
+/* a7  update_inactive_features (sae.py:165-169) + feature-major index of the selection.
+ * col_ptr[D+1]; csc_row[nnz] batch row of each entry; csc_pos[nnz] its position in the CSR
+ * arrays.  cnt (float[D]) += 1 where the feature did not fire, = 0 where it did (NULL = skip).
+ * Entries of a feature are ordered by batch row (deterministic accumulation order downstream).
+ * workspace: mtc_csc_workspace_bytes(). */
+size_t mtc_csc_workspace_bytes(const mtc_desc* d);
+int mtc_build_csc(const mtc_desc* d, const int32_t* row_ptr, const int32_t* col_idx,
+                  void* workspace, size_t workspace_bytes, int32_t* col_ptr, int32_t* csc_row,
+                  int32_t* csc_pos, float* cnt, void* stream);
+
+/* a11  k-sparse backward (autograd of sae.py:173-245, training.py:172), one wavefront per feature:
+ *   dW_dec[j]  = scale * sum_b a_bj g_b          dW_encT[j] = scale * sum_b d_a_bj x_b
+ *   db_enc[j]  = scale * sum_b d_a_bj            db_dec     = scale * sum_b g_b
+ * grads are dense [D][A] in the model dtype (rows of silent features are written as zeros);
+ * `scale` points to the upstream d loss (device float, NULL = 1).  accumulate != 0 adds into the
+ * existing gradient buffers (used for the aux contributions). */
+int mtc_backward_sparse(const mtc_desc* d, const int32_t* col_ptr, const int32_t* csc_row,
+                        const int32_t* csc_pos, const void* vals, const float* d_vals,
+                        const float* g, const void* x_norm, const float* scale, void* dW_dec,
+                        void* dW_encT, void* db_enc, int accumulate, void* stream);
+size_t mtc_colsum_workspace_bytes(const mtc_desc* d);
+int mtc_colsum(const mtc_desc* d, const float* g, const float* scale, void* workspace,
+               size_t workspace_bytes, void* db_dec, int accumulate, void* stream);
+
+/* a12 + a13  make_decoder_weights_and_grad_unit_norm (sae.py:155-163) fused with torch.optim.Adam
+ * (training.py:60,178; betas, eps 1e-8, no weight decay), op-by-op rounding in the parameter
+ * dtype like PyTorch's single-tensor Adam.  `step` is 1-based.  Moments are in the param dtype. */
+typedef struct mtc_adam_hyper {
+    double lr, beta1, beta2, eps;   /* host doubles: bias corrections are formed in double like PyTorch */
+    int32_t step;
+    int32_t pad;
+} mtc_adam_hyper;
+int mtc_unitnorm_adam_rows(const mtc_desc* d, void* W_dec, void* grad, void* exp_avg,
+                           void* exp_avg_sq, const mtc_adam_hyper* h_host, int write_grad,
+                           void* stream);
+int mtc_adam_flat(int32_t dtype, size_t n, void* p, const void* grad, void* exp_avg,
+                  void* exp_avg_sq, const mtc_adam_hyper* h_host, void* stream);
+/* projection only (the reference method called on its own, sae.py:155-163) */
+int mtc_unitnorm_project(const mtc_desc* d, void* W_dec, void* grad, void* stream);
+
+/* a15 helpers: CSR <-> dense [B][D] in the model dtype (encode returns dense, decode takes it) */
+int mtc_densify(const mtc_desc* d, const int32_t* row_ptr, const int32_t* col_idx, const void* vals,
+                int32_t max_col, void* dense, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MTC_H */

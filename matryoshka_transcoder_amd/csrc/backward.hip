@@ -1,0 +1,315 @@
+// K4: k-sparse backward (autograd of sae.py:173-245 as driven by training.py:172) and the
+// feature-major index it needs; dead-feature counters (sae.py:165-169).
+//
+// The selected entries are re-indexed by FEATURE (CSC).  One wavefront per feature j then builds
+//     dW_dec[j]  = sum_b a_bj  * g_b        (gathers rows of g,      [B][A_t] fp32)
+//     dW_encT[j] = sum_b da_bj * x_b        (gathers rows of x_norm, [B][A_s] model dtype)
+// in registers and writes each gradient row exactly once -- no float atomics, rows of silent
+// features are written as zeros, so the dense gradient the optimizer expects costs no extra pass.
+// The gathered operands (g: B*A_t*4 B, x: B*A_s*s B) are small enough to live in L2 / Infinity
+// Cache; algorithmic bytes = nnz*(A_t*4 + A_s*s) gathered + D*(A_t + A_s)*s written.
+#include "common.hpp"
+
+namespace mtc {
+
+// ---------------------------------------------------------------- CSC build
+// wave per row: count entries per feature
+__global__ __launch_bounds__(256) void csc_count_kernel(int B, const int32_t* __restrict__ row_ptr,
+                                                        const int32_t* __restrict__ col_idx, uint32_t* __restrict__ cnt) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B) return;
+    for (int e = row_ptr[row] + lane; e < row_ptr[row + 1]; e += 64) atomicAdd(&cnt[col_idx[e]], 1u);
+}
+
+// one workgroup: exclusive scan over D counts -> col_ptr, cursor copy, dead-counter update
+__global__ __launch_bounds__(1024) void csc_scan_kernel(int D, const uint32_t* __restrict__ cnt, int32_t* __restrict__ col_ptr,
+                                                        uint32_t* __restrict__ cursor, float* __restrict__ dead_cnt) {
+    __shared__ uint32_t sm[16];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int per = (D + 1023) / 1024;
+    const int j0 = t * per, j1 = min(D, j0 + per);
+    uint32_t mine = 0;
+    for (int j = j0; j < j1; ++j) mine += cnt[j];
+    uint32_t inc = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t n = __shfl_up(inc, o, 64); if (lane >= o) inc += n; }
+    if (lane == 63) sm[w] = inc;
+    __syncthreads();
+    uint32_t base = inc - mine, total = 0;
+    for (int i = 0; i < 16; ++i) { if (i < w) base += sm[i]; total += sm[i]; }
+    for (int j = j0; j < j1; ++j) {
+        const uint32_t c = cnt[j];
+        col_ptr[j] = (int32_t)base;
+        cursor[j] = base;
+        if (dead_cnt) dead_cnt[j] = c ? 0.f : dead_cnt[j] + 1.f;
+        base += c;
+    }
+    if (t == 0) col_ptr[D] = (int32_t)total;
+}
+
+__global__ __launch_bounds__(256) void csc_fill_kernel(int B, const int32_t* __restrict__ row_ptr,
+                                                       const int32_t* __restrict__ col_idx, uint32_t* __restrict__ cursor,
+                                                       int32_t* __restrict__ csc_row, int32_t* __restrict__ csc_pos) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B) return;
+    for (int e = row_ptr[row] + lane; e < row_ptr[row + 1]; e += 64) {
+        const uint32_t pos = atomicAdd(&cursor[col_idx[e]], 1u);
+        csc_row[pos] = row;
+        csc_pos[pos] = e;
+    }
+}
+
+// Entries of one feature arrive in atomic order; sort each segment by batch row so that the
+// fp32 accumulation order (and therefore every gradient bit) is reproducible run to run.
+// One wave per feature; segments <= 64 are sorted by rank counting in registers.
+__global__ __launch_bounds__(256) void csc_sort_kernel(int D, const int32_t* __restrict__ col_ptr,
+                                                       int32_t* __restrict__ csc_row, int32_t* __restrict__ csc_pos) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= D) return;
+    const int s = col_ptr[j], n = col_ptr[j + 1] - s;
+    if (n <= 1) return;
+    if (n <= 64) {
+        const int r = lane < n ? csc_row[s + lane] : 0x7fffffff;
+        const int p = lane < n ? csc_pos[s + lane] : 0;
+        int rank = 0;
+        for (int i = 0; i < n; ++i) rank += (__builtin_amdgcn_readlane(r, i) < r) ? 1 : 0;   // rows are unique per feature
+        if (lane < n) { csc_row[s + rank] = r; csc_pos[s + rank] = p; }
+        return;
+    }
+    // longer segments: csc_sort_long_kernel
+}
+
+// Long segments (> 64 entries): one workgroup per such feature, bitmap-by-row in LDS, then an ordered sweep.
+// rows < B <= 65536.  slot[r] = csc_pos for row r (or -1).
+__global__ __launch_bounds__(256) void csc_sort_long_kernel(int D, int B, const int32_t* __restrict__ col_ptr,
+                                                            int32_t* __restrict__ csc_row, int32_t* __restrict__ csc_pos,
+                                                            int32_t* __restrict__ slot_ws /* gridDim.x * B ints */) {
+    __shared__ uint32_t wsum[4];
+    int32_t* slot = slot_ws + (size_t)blockIdx.x * B;
+    for (int j = blockIdx.x; j < D; j += gridDim.x) {
+        const int s = col_ptr[j], n = col_ptr[j + 1] - s;
+        if (n <= 64) continue;                                  // uniform per block
+        for (int r = threadIdx.x; r < B; r += 256) slot[r] = -1;
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += 256) slot[csc_row[s + i]] = csc_pos[s + i];
+        __syncthreads();
+        // ordered compaction of the occupied rows
+        uint32_t out = 0;
+        for (int r0 = 0; r0 < B; r0 += 256) {
+            const int r = r0 + threadIdx.x;
+            const int v = r < B ? slot[r] : -1;
+            const uint64_t bal = __ballot(v >= 0);
+            const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+            if (lane == 0) wsum[w] = (uint32_t)__popcll(bal);
+            __syncthreads();
+            uint32_t pre = 0, tot = 0;
+            for (int i = 0; i < 4; ++i) { if (i < w) pre += wsum[i]; tot += wsum[i]; }
+            if (v >= 0) {
+                const uint32_t pos = out + pre + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+                csc_row[s + pos] = r;
+                csc_pos[s + pos] = v;
+            }
+            out += tot;
+            __syncthreads();
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------- gradient rows
+// out[j][:] = scale * sum_{e in feature j} coef[csc_pos[e]] * src[csc_row[e]][:]
+// SRC_DT: dtype of the gathered rows; OUT_DT: gradient dtype; COEF_DT: dtype of coef (vals are model dtype,
+// d_vals fp32).  bias_out (optional) = scale * sum coef.
+template <int SRC_DT, int OUT_DT, int COEF_DT, int NC>
+__global__ __launch_bounds__(256) void grad_rows_kernel(int D, int A, const int32_t* __restrict__ col_ptr,
+                                                        const int32_t* __restrict__ csc_row, const int32_t* __restrict__ csc_pos,
+                                                        const void* __restrict__ coef, const void* __restrict__ src,
+                                                        const float* __restrict__ scale_p, void* __restrict__ out,
+                                                        void* __restrict__ bias_out, int accumulate) {
+    typedef DType<OUT_DT> O_;
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= D) return;
+    const int nch = A >> 3;
+    const float scale = scale_p ? *scale_p : 1.f;
+    float acc[NC][8];
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[c][k] = 0.f;
+    float csum = 0.f;
+    const int s = col_ptr[j], e_end = col_ptr[j + 1];
+    for (int e0 = s; e0 < e_end; e0 += 64) {
+        const int nb = min(64, e_end - e0);
+        int my_row = 0; float my_c = 0.f;
+        if (lane < nb) {
+            my_row = csc_row[e0 + lane];
+            const int pos = csc_pos[e0 + lane];
+            my_c = DType<COEF_DT>::ld(reinterpret_cast<const typename DType<COEF_DT>::T*>(coef) + pos);
+        }
+        csum += my_c;
+        for (int i = 0; i < nb; ++i) {
+            const int r = __builtin_amdgcn_readlane(my_row, i);
+            const float a = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_c), i));
+            const size_t rowoff = (size_t)r * A;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                if (lane + 64 * c < nch) {
+                    float w[8];
+                    load8<SRC_DT>(src, rowoff + (size_t)(lane + 64 * c) * 8, w);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc[c][k] = fmaf(a, w[k], acc[c][k]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        if (lane + 64 * c < nch) {
+            const size_t off = (size_t)j * A + (size_t)(lane + 64 * c) * 8;
+            float o[8];
+            if (accumulate) {
+                load8<OUT_DT>(out, off, o);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) o[k] = O_::rnd(o[k] + scale * acc[c][k]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) o[k] = scale * acc[c][k];
+            }
+            store8<OUT_DT>(out, off, o);
+        }
+    }
+    if (bias_out) {
+        csum = wave_sum(csum);
+        if (lane == 0) {
+            typename O_::T* bp = reinterpret_cast<typename O_::T*>(bias_out) + j;
+            O_::st(bp, accumulate ? O_::ld(bp) + scale * csum : scale * csum);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- db_dec = sum_b g_b
+__global__ __launch_bounds__(256) void colsum_partial_kernel(int B, int A, const float* __restrict__ g, int rows_per_slab,
+                                                             float* __restrict__ partial) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    const int slab = blockIdx.y;
+    if (col >= A) return;
+    const int r0 = slab * rows_per_slab, r1 = min(B, r0 + rows_per_slab);
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) s += g[(size_t)r * A + col];
+    partial[(size_t)slab * A + col] = s;
+}
+template <int DT>
+__global__ __launch_bounds__(256) void colsum_finish_kernel(int A, int slabs, const float* __restrict__ partial,
+                                                            const float* __restrict__ scale_p, void* __restrict__ out,
+                                                            int accumulate) {
+    typedef DType<DT> D_;
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= A) return;
+    float s = 0.f;
+    for (int i = 0; i < slabs; ++i) s += partial[(size_t)i * A + col];
+    s *= scale_p ? *scale_p : 1.f;
+    typename D_::T* p = reinterpret_cast<typename D_::T*>(out) + col;
+    D_::st(p, accumulate ? D_::ld(p) + s : s);
+}
+
+}  // namespace mtc
+
+using namespace mtc;
+
+static int nc_for(int A) { return ((A >> 3) + 63) / 64; }
+static int long_sort_blocks() { return 64; }
+
+extern "C" size_t mtc_csc_workspace_bytes(const mtc_desc* d) {
+    if (!d) return 0;
+    // counts[D] + cursor[D] + long-segment row slots
+    return 2 * (size_t)d->D * sizeof(uint32_t) + (size_t)long_sort_blocks() * d->B * sizeof(int32_t);
+}
+
+extern "C" int mtc_build_csc(const mtc_desc* d, const int32_t* row_ptr, const int32_t* col_idx, void* workspace,
+                             size_t workspace_bytes, int32_t* col_ptr, int32_t* csc_row, int32_t* csc_pos, float* cnt,
+                             void* stream) {
+    if (check_desc(d, "mtc_build_csc")) return -1;
+    MTC_REQUIRE(row_ptr && col_idx && workspace && col_ptr && csc_row && csc_pos, "mtc_build_csc: null pointer");
+    MTC_REQUIRE(workspace_bytes >= mtc_csc_workspace_bytes(d), "mtc_build_csc: workspace too small");
+    MTC_REQUIRE(d->B <= 65536, "mtc_build_csc: B > 65536 unsupported");
+    uint32_t* counts = reinterpret_cast<uint32_t*>(workspace);
+    uint32_t* cursor = counts + d->D;
+    int32_t* slots = reinterpret_cast<int32_t*>(cursor + d->D);
+    hipStream_t s = as_stream(stream);
+    if (hipMemsetAsync(counts, 0, (size_t)d->D * sizeof(uint32_t), s) != hipSuccess) {
+        set_error("mtc_build_csc: memset failed");
+        return -2;
+    }
+    const dim3 rgrid((d->B + 3) / 4), block(256);
+    hipLaunchKernelGGL(csc_count_kernel, rgrid, block, 0, s, d->B, row_ptr, col_idx, counts);
+    hipLaunchKernelGGL(csc_scan_kernel, dim3(1), dim3(1024), 0, s, d->D, counts, col_ptr, cursor, cnt);
+    hipLaunchKernelGGL(csc_fill_kernel, rgrid, block, 0, s, d->B, row_ptr, col_idx, cursor, csc_row, csc_pos);
+    hipLaunchKernelGGL(csc_sort_kernel, dim3((d->D + 3) / 4), block, 0, s, d->D, col_ptr, csc_row, csc_pos);
+    hipLaunchKernelGGL(csc_sort_long_kernel, dim3(long_sort_blocks()), block, 0, s, d->D, d->B, col_ptr, csc_row, csc_pos,
+                       slots);
+    return check_launch("mtc_build_csc");
+}
+
+#define LAUNCH_GRAD(SRC, OUT, COEF, ncv)                                                                             \
+    do {                                                                                                             \
+        const int nc_ = (ncv);                                                                                       \
+        if (nc_ <= 1) hipLaunchKernelGGL((grad_rows_kernel<SRC, OUT, COEF, 1>), grid, block, 0, s, D, A, col_ptr, csc_row, csc_pos, coef, src, scale, out, bias_out, accumulate); \
+        else if (nc_ <= 2) hipLaunchKernelGGL((grad_rows_kernel<SRC, OUT, COEF, 2>), grid, block, 0, s, D, A, col_ptr, csc_row, csc_pos, coef, src, scale, out, bias_out, accumulate); \
+        else if (nc_ <= 3) hipLaunchKernelGGL((grad_rows_kernel<SRC, OUT, COEF, 3>), grid, block, 0, s, D, A, col_ptr, csc_row, csc_pos, coef, src, scale, out, bias_out, accumulate); \
+        else if (nc_ <= 5) hipLaunchKernelGGL((grad_rows_kernel<SRC, OUT, COEF, 5>), grid, block, 0, s, D, A, col_ptr, csc_row, csc_pos, coef, src, scale, out, bias_out, accumulate); \
+        else if (nc_ <= 7) hipLaunchKernelGGL((grad_rows_kernel<SRC, OUT, COEF, 7>), grid, block, 0, s, D, A, col_ptr, csc_row, csc_pos, coef, src, scale, out, bias_out, accumulate); \
+        else if (nc_ <= 9) hipLaunchKernelGGL((grad_rows_kernel<SRC, OUT, COEF, 9>), grid, block, 0, s, D, A, col_ptr, csc_row, csc_pos, coef, src, scale, out, bias_out, accumulate); \
+        else hipLaunchKernelGGL((grad_rows_kernel<SRC, OUT, COEF, 16>), grid, block, 0, s, D, A, col_ptr, csc_row, csc_pos, coef, src, scale, out, bias_out, accumulate); \
+    } while (0)
+
+static void launch_grad_rows(int dtype, bool src_is_g, int D, int A, const int32_t* col_ptr, const int32_t* csc_row,
+                             const int32_t* csc_pos, const void* coef, const void* src, const float* scale, void* out,
+                             void* bias_out, int accumulate, hipStream_t s) {
+    const dim3 grid((D + 3) / 4), block(256);
+    const int nc = nc_for(A);
+    if (src_is_g) {          // dW_dec: src = g (fp32), coef = vals (model dtype)
+        if (dtype == MTC_BF16) LAUNCH_GRAD(MTC_F32, MTC_BF16, MTC_BF16, nc);
+        else LAUNCH_GRAD(MTC_F32, MTC_F32, MTC_F32, nc);
+    } else {                 // dW_encT: src = x_norm (model dtype), coef = d_vals (fp32)
+        if (dtype == MTC_BF16) LAUNCH_GRAD(MTC_BF16, MTC_BF16, MTC_F32, nc);
+        else LAUNCH_GRAD(MTC_F32, MTC_F32, MTC_F32, nc);
+    }
+}
+
+extern "C" int mtc_backward_sparse(const mtc_desc* d, const int32_t* col_ptr, const int32_t* csc_row,
+                                   const int32_t* csc_pos, const void* vals, const float* d_vals, const float* g,
+                                   const void* x_norm, const float* scale, void* dW_dec, void* dW_encT, void* db_enc,
+                                   int accumulate, void* stream) {
+    if (check_desc(d, "mtc_backward_sparse")) return -1;
+    MTC_REQUIRE(col_ptr && csc_row && csc_pos && vals && d_vals && g && x_norm && dW_dec && dW_encT && db_enc,
+                "mtc_backward_sparse: null pointer");
+    hipStream_t s = as_stream(stream);
+    launch_grad_rows(d->dtype, true, d->D, d->A_t, col_ptr, csc_row, csc_pos, vals, g, scale, dW_dec, nullptr, accumulate, s);
+    launch_grad_rows(d->dtype, false, d->D, d->A_s, col_ptr, csc_row, csc_pos, d_vals, x_norm, scale, dW_encT, db_enc,
+                     accumulate, s);
+    return check_launch("mtc_backward_sparse");
+}
+
+extern "C" size_t mtc_colsum_workspace_bytes(const mtc_desc* d) { return d ? 32 * (size_t)d->A_t * sizeof(float) : 0; }
+
+extern "C" int mtc_colsum(const mtc_desc* d, const float* g, const float* scale, void* workspace, size_t workspace_bytes,
+                          void* db_dec, int accumulate, void* stream) {
+    if (check_desc(d, "mtc_colsum")) return -1;
+    MTC_REQUIRE(g && workspace && db_dec, "mtc_colsum: null pointer");
+    MTC_REQUIRE(workspace_bytes >= mtc_colsum_workspace_bytes(d), "mtc_colsum: workspace too small");
+    const int slabs = 32, rows_per = (d->B + slabs - 1) / slabs;
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((d->A_t + 255) / 256, slabs), dim3(256), 0, s, d->B, d->A_t, g, rows_per,
+                       reinterpret_cast<float*>(workspace));
+    if (d->dtype == MTC_BF16)
+        hipLaunchKernelGGL(colsum_finish_kernel<MTC_BF16>, dim3((d->A_t + 255) / 256), dim3(256), 0, s, d->A_t, slabs,
+                           reinterpret_cast<const float*>(workspace), scale, db_dec, accumulate);
+    else
+        hipLaunchKernelGGL(colsum_finish_kernel<MTC_F32>, dim3((d->A_t + 255) / 256), dim3(256), 0, s, d->A_t, slabs,
+                           reinterpret_cast<const float*>(workspace), scale, db_dec, accumulate);
+    return check_launch("mtc_colsum");
+}

@@ -1,0 +1,418 @@
+// K2: global batch-TopK (sae.py:176-187) as an exact k-th-largest threshold select, the eval-mode
+// threshold select (sae.py:189-191) and the threshold EMA (sae.py:349-361).
+//
+// ReLU outputs are >= 0, and the float bit pattern of a positive float is order preserving, so the
+// k-th largest value is found by a most-significant-bits-first radix select over the bit pattern:
+//   level 0: bits [30:19] (12 bits)   level 1: bits [18:7]   level 2: bits [6:0]   (bf16: 2 levels)
+// Each level is one streaming pass that builds a 4096-bin histogram (LDS atomics per workgroup,
+// then global atomics for the non-empty bins) followed by a one-workgroup suffix scan.  The
+// histograms are additive, so a feature-sharded caller all-reduces them between the two kernels.
+// With tau known, one wavefront per batch row counts (> tau, == tau), a one-workgroup scan turns
+// the counts into CSR offsets and a per-row tie quota (ties are taken in ascending flat-index
+// order until k are selected), and one wavefront per row compacts its selected entries in
+// ascending column order (= prefix-group order).  Everything stays on the device.
+#include "common.hpp"
+
+namespace mtc {
+
+constexpr int HIST_BINS = 4096;
+
+__device__ __forceinline__ int level_shift(int level) { return level == 0 ? 19 : (level == 1 ? 7 : 0); }
+__device__ __forceinline__ uint32_t level_mask(int level) { return level == 2 ? 0x7fu : 0xfffu; }
+// bits above the level's field (must match the prefix fixed so far)
+__device__ __forceinline__ uint32_t level_prefix_mask(int level) {
+    return level == 0 ? 0u : (level == 1 ? 0xfff80000u : 0xffffff80u);
+}
+
+__global__ void select_init_kernel(mtc_select_state* st, uint32_t k_total) {
+    if (threadIdx.x == 0) {
+        st->key_prefix = 0; st->k_rem = k_total; st->all_pos = 0; st->n_gt = 0;
+        st->tau_bits = 0; st->n_tie_take = 0; st->min_sel_bits = 0xffffffffu; st->nnz = 0;
+        for (int i = 0; i < 8; ++i) st->pad[i] = 0;
+    }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void select_hist_kernel(const void* __restrict__ acts, size_t n_chunks, int level,
+                                                          const mtc_select_state* __restrict__ st,
+                                                          uint32_t* __restrict__ hist) {
+    __shared__ uint32_t lh[HIST_BINS];
+    for (int i = threadIdx.x; i < HIST_BINS; i += 256) lh[i] = 0;
+    __syncthreads();
+    const uint32_t all_pos = st->all_pos;
+    const uint32_t prefix = st->key_prefix;
+    const int sh = level_shift(level);
+    const uint32_t fm = level_mask(level), pm = level_prefix_mask(level);
+    if (!(all_pos && level > 0)) {
+        for (size_t c = (size_t)blockIdx.x * 256 + threadIdx.x; c < n_chunks; c += (size_t)gridDim.x * 256) {
+            uint32_t keys[8];
+            if (DT == MTC_BF16) {
+                const u32x4 r = reinterpret_cast<const u32x4*>(acts)[c];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { keys[2 * i] = r[i] << 16; keys[2 * i + 1] = r[i] & 0xffff0000u; }
+            } else {
+                const u32x4 a = reinterpret_cast<const u32x4*>(acts)[2 * c], b = reinterpret_cast<const u32x4*>(acts)[2 * c + 1];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { keys[i] = a[i]; keys[4 + i] = b[i]; }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const uint32_t k = keys[i];
+                // positive, finite-or-inf, not NaN, and (levels > 0) inside the bin chosen so far
+                if (k != 0 && k <= 0x7f800000u && ((k ^ prefix) & pm) == 0) atomicAdd(&lh[(k >> sh) & fm], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < HIST_BINS; i += 256) {
+        const uint32_t v = lh[i];
+        if (v) atomicAdd(&hist[i], v);
+    }
+}
+
+// one workgroup of 1024 threads: suffix scan over 4096 bins, pick the bin holding the k_rem-th largest
+__global__ __launch_bounds__(1024) void select_scan_kernel(const uint32_t* __restrict__ hist, int level, int last_level,
+                                                           mtc_select_state* st) {
+    __shared__ uint32_t part[1024];
+    __shared__ uint32_t found_bin, found_above;
+    const int t = threadIdx.x;
+    if (st->all_pos) return;                           // uniform: whole block leaves
+    // thread t owns bins [4t, 4t+3]; "above" = higher bin index
+    const uint32_t h0 = hist[4 * t], h1 = hist[4 * t + 1], h2 = hist[4 * t + 2], h3 = hist[4 * t + 3];
+    part[t] = h0 + h1 + h2 + h3;
+    if (t == 0) { found_bin = 0xffffffffu; found_above = 0; }
+    __syncthreads();
+    // inclusive suffix sum over threads (Hillis-Steele on 1024 entries)
+    for (int off = 1; off < 1024; off <<= 1) {
+        const uint32_t add = (t + off < 1024) ? part[t + off] : 0u;
+        __syncthreads();
+        part[t] += add;
+        __syncthreads();
+    }
+    const uint32_t k_rem = st->k_rem;
+    const uint32_t above_thread = (t + 1 < 1024) ? part[t + 1] : 0u;   // count in bins above this thread's 4
+    // walk my 4 bins from the top
+    uint32_t above = above_thread;
+    const uint32_t hs[4] = {h0, h1, h2, h3};
+#pragma unroll
+    for (int i = 3; i >= 0; --i) {
+        if (above < k_rem && k_rem <= above + hs[i]) { found_bin = 4 * t + i; found_above = above; }
+        above += hs[i];
+    }
+    __syncthreads();
+    if (t == 0) {
+        const uint32_t total = part[0];
+        if (found_bin == 0xffffffffu) {
+            // fewer than k_rem candidates: only possible at level 0 (fewer positives than k)
+            st->all_pos = 1; st->n_gt = total; st->tau_bits = 0; st->n_tie_take = 0; st->k_rem = 0;
+        } else {
+            st->n_gt += found_above;
+            st->k_rem = k_rem - found_above;
+            st->key_prefix |= found_bin << level_shift(level);
+            if (level == last_level) { st->tau_bits = st->key_prefix; st->n_tie_take = st->k_rem; }
+        }
+    }
+}
+
+// wave per row: counts of (> tau) and (== tau); threshold mode: (> thr) only
+template <int DT>
+__global__ __launch_bounds__(256) void select_count_kernel(const void* __restrict__ acts, int B, int D,
+                                                           mtc_select_state* __restrict__ st,
+                                                           const void* __restrict__ threshold,
+                                                           uint32_t* __restrict__ row_gt, uint32_t* __restrict__ row_eq) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B) return;
+    float tau; bool ties = false;
+    if (threshold) tau = fmaxf(DType<DT>::ld(reinterpret_cast<const typename DType<DT>::T*>(threshold)), 0.f);
+    else if (st->all_pos) tau = 0.f;
+    else { tau = __uint_as_float(st->tau_bits); ties = true; }
+    const size_t base = (size_t)row * D;
+    uint32_t gt = 0, eq = 0, mn = 0xffffffffu;
+    for (int c = lane; c < (D >> 3); c += 64) {
+        float v[8];
+        load8<DT>(acts, base + (size_t)c * 8, v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (v[i] > tau) { ++gt; mn = min(mn, __float_as_uint(v[i])); }
+            else if (ties && v[i] == tau) ++eq;
+        }
+    }
+    gt = wave_sum_u32(gt); eq = wave_sum_u32(eq);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, o, 64));
+    if (lane == 0) {
+        row_gt[row] = gt; row_eq[row] = eq;
+        if (mn != 0xffffffffu) atomicMin(&st->min_sel_bits, mn);
+    }
+}
+
+// block-wide exclusive scan helper (1024 threads); returns exclusive prefix of v, total in *total
+__device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t* sm /*[16]*/, uint32_t* total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t n = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += n;
+    }
+    if (lane == 63) sm[w] = inc;
+    __syncthreads();
+    uint32_t wbase = 0, tot = 0;
+    for (int i = 0; i < 16; ++i) { const uint32_t s = sm[i]; if (i < w) wbase += s; tot += s; }
+    __syncthreads();
+    *total = tot;
+    return wbase + inc - v;
+}
+
+__global__ __launch_bounds__(1024) void select_offsets_kernel(int B, const uint32_t* __restrict__ row_gt,
+                                                              const uint32_t* __restrict__ row_eq,
+                                                              const uint32_t* __restrict__ tie_before_in,
+                                                              mtc_select_state* st, int32_t* __restrict__ row_ptr,
+                                                              uint32_t* __restrict__ tie_take) {
+    __shared__ uint32_t sm[16];
+    const int t = threadIdx.x;
+    const int per = (B + 1023) / 1024;
+    const int r0 = t * per, r1 = min(B, r0 + per);
+    const uint32_t quota = st->n_tie_take;
+    // pass 1: ties preceding each row
+    uint32_t my_eq = 0;
+    for (int r = r0; r < r1; ++r) my_eq += row_eq[r];
+    uint32_t tot;
+    uint32_t eq_base = block_excl_scan_1024(my_eq, sm, &tot);
+    // pass 2: quota per row, nnz per row
+    uint32_t my_nnz = 0;
+    uint32_t run = eq_base;
+    for (int r = r0; r < r1; ++r) {
+        const uint32_t e = row_eq[r];
+        const uint32_t before = tie_before_in ? tie_before_in[r] : run;
+        const uint32_t take = before >= quota ? 0u : min(e, quota - before);
+        tie_take[r] = take;
+        my_nnz += row_gt[r] + take;
+        run += e;
+    }
+    uint32_t nnz_total;
+    uint32_t base = block_excl_scan_1024(my_nnz, sm, &nnz_total);
+    for (int r = r0; r < r1; ++r) {
+        row_ptr[r] = (int32_t)base;
+        base += row_gt[r] + tie_take[r];
+    }
+    if (t == 0) {
+        row_ptr[B] = (int32_t)nnz_total;
+        st->nnz = nnz_total;
+        if (quota > 0) st->min_sel_bits = min(st->min_sel_bits, st->tau_bits);
+    }
+}
+
+// wave per row: ordered compaction of the selected entries
+template <int DT>
+__global__ __launch_bounds__(256) void select_fill_kernel(const void* __restrict__ acts, int B, int D,
+                                                          const mtc_select_state* __restrict__ st,
+                                                          const void* __restrict__ threshold,
+                                                          const int32_t* __restrict__ row_ptr,
+                                                          const uint32_t* __restrict__ tie_take,
+                                                          int32_t* __restrict__ col_idx, void* __restrict__ vals) {
+    typedef typename DType<DT>::T T;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B) return;
+    float tau; uint32_t quota = 0;
+    if (threshold) tau = fmaxf(DType<DT>::ld(reinterpret_cast<const T*>(threshold)), 0.f);
+    else if (st->all_pos) tau = 0.f;
+    else { tau = __uint_as_float(st->tau_bits); quota = tie_take[row]; }
+    const size_t base = (size_t)row * D;
+    uint32_t out = (uint32_t)row_ptr[row];
+    uint32_t ties_seen = 0;                             // wave-uniform running count of == tau in this row
+    T* vout = reinterpret_cast<T*>(vals);
+    for (int c0 = 0; c0 < (D >> 3); c0 += 64) {
+        const int c = c0 + lane;
+        float v[8];
+        uint32_t gtm = 0, eqm = 0;
+        if (c < (D >> 3)) {
+            load8<DT>(acts, base + (size_t)c * 8, v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (v[i] > tau) gtm |= 1u << i;
+                else if (quota && v[i] == tau) eqm |= 1u << i;
+            }
+        }
+        const uint64_t any = __ballot((gtm | eqm) != 0);
+        if (any == 0) continue;                          // wave-uniform
+        uint32_t selm = gtm;
+        if (quota && __ballot(eqm != 0)) {
+            // tie rank = ties in earlier lanes + ties seen in earlier iterations
+            const uint32_t ne = __popc(eqm);
+            uint32_t inc = ne;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t n = __shfl_up(inc, o, 64); if (lane >= o) inc += n; }
+            uint32_t rank = ties_seen + inc - ne;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (eqm & (1u << i)) { if (rank < quota) selm |= 1u << i; ++rank; }
+            ties_seen += __shfl(inc, 63, 64);
+        }
+        const uint32_t ns = __popc(selm);
+        uint32_t inc = ns;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t n = __shfl_up(inc, o, 64); if (lane >= o) inc += n; }
+        uint32_t pos = out + inc - ns;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (selm & (1u << i)) {
+                col_idx[pos] = c * 8 + i;
+                DType<DT>::st(vout + pos, v[i]);
+                ++pos;
+            }
+        out += __shfl(inc, 63, 64);
+    }
+}
+
+template <int DT>
+__global__ void threshold_ema_kernel(const mtc_select_state* __restrict__ st, void* threshold, float lr) {
+    typedef DType<DT> D_;
+    typedef typename D_::T T;
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (st->nnz == 0 || st->min_sel_bits == 0xffffffffu) return;     // "if positive_mask.any()"
+    T* p = reinterpret_cast<T*>(threshold);
+    const float thr = D_::ld(p);
+    const float mn = __uint_as_float(st->min_sel_bits);
+    // (1 - lr) * threshold + lr * min_positive, each op rounded to the buffer dtype
+    const float a = D_::rnd((float)(1.0 - (double)lr) * thr);
+    const float b = D_::rnd(lr * mn);
+    D_::st(p, D_::rnd(a + b));
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void densify_kernel(const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col_idx,
+                                                      const void* __restrict__ vals, int B, int D, int max_col,
+                                                      void* __restrict__ dense) {
+    typedef typename DType<DT>::T T;
+    const int row = blockIdx.x;
+    T* out = reinterpret_cast<T*>(dense) + (size_t)row * D;
+    for (int c = threadIdx.x; c < (D >> 3); c += 256) {
+        const float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        store8<DT>(out, (size_t)c * 8, z);
+    }
+    __syncthreads();
+    const T* v = reinterpret_cast<const T*>(vals);
+    for (int e = row_ptr[row] + threadIdx.x; e < row_ptr[row + 1]; e += 256) {
+        const int c = col_idx[e];
+        if (c < max_col) out[c] = v[e];
+    }
+}
+
+}  // namespace mtc
+
+using namespace mtc;
+
+#define DISPATCH_DT(dt, KERNEL, grid, block, shmem, stream, ...)                                      \
+    do {                                                                                              \
+        if ((dt) == MTC_BF16) hipLaunchKernelGGL(KERNEL<MTC_BF16>, grid, block, shmem, stream, __VA_ARGS__); \
+        else hipLaunchKernelGGL(KERNEL<MTC_F32>, grid, block, shmem, stream, __VA_ARGS__);            \
+    } while (0)
+
+extern "C" int mtc_select_levels(const mtc_desc* d) { return d && d->dtype == MTC_BF16 ? 2 : 3; }
+
+extern "C" int mtc_select_init(mtc_select_state* st, uint32_t k_total, void* stream) {
+    MTC_REQUIRE(st, "mtc_select_init: null state");
+    hipLaunchKernelGGL(select_init_kernel, dim3(1), dim3(64), 0, as_stream(stream), st, k_total);
+    return check_launch("mtc_select_init");
+}
+
+extern "C" int mtc_select_hist(const mtc_desc* d, const void* acts, int level, const mtc_select_state* st,
+                               uint32_t* hist, void* stream) {
+    if (check_desc(d, "mtc_select_hist")) return -1;
+    MTC_REQUIRE(acts && st && hist, "mtc_select_hist: null pointer");
+    MTC_REQUIRE(level >= 0 && level < mtc_select_levels(d), "mtc_select_hist: bad level %d", level);
+    const size_t n_chunks = (size_t)d->B * d->D / 8;
+    const int grid = (int)std::min<size_t>((n_chunks + 255) / 256, 2048);
+    DISPATCH_DT(d->dtype, select_hist_kernel, dim3(grid), dim3(256), 0, as_stream(stream), acts, n_chunks, level, st, hist);
+    return check_launch("mtc_select_hist");
+}
+
+extern "C" int mtc_select_scan(const mtc_desc* d, int level, const uint32_t* hist, mtc_select_state* st, void* stream) {
+    if (check_desc(d, "mtc_select_scan")) return -1;
+    MTC_REQUIRE(hist && st, "mtc_select_scan: null pointer");
+    hipLaunchKernelGGL(select_scan_kernel, dim3(1), dim3(1024), 0, as_stream(stream), hist, level,
+                       mtc_select_levels(d) - 1, st);
+    return check_launch("mtc_select_scan");
+}
+
+extern "C" int mtc_select_count(const mtc_desc* d, const void* acts, const mtc_select_state* st, const void* threshold,
+                                uint32_t* row_gt, uint32_t* row_eq, void* stream) {
+    if (check_desc(d, "mtc_select_count")) return -1;
+    MTC_REQUIRE(acts && st && row_gt && row_eq, "mtc_select_count: null pointer");
+    DISPATCH_DT(d->dtype, select_count_kernel, dim3((d->B + 3) / 4), dim3(256), 0, as_stream(stream), acts, d->B, d->D,
+                const_cast<mtc_select_state*>(st), threshold, row_gt, row_eq);
+    return check_launch("mtc_select_count");
+}
+
+extern "C" int mtc_select_offsets(const mtc_desc* d, const uint32_t* row_gt, const uint32_t* row_eq,
+                                  const uint32_t* tie_before, mtc_select_state* st, int32_t* row_ptr,
+                                  uint32_t* tie_take, void* stream) {
+    if (check_desc(d, "mtc_select_offsets")) return -1;
+    MTC_REQUIRE(row_gt && row_eq && st && row_ptr && tie_take, "mtc_select_offsets: null pointer");
+    hipLaunchKernelGGL(select_offsets_kernel, dim3(1), dim3(1024), 0, as_stream(stream), d->B, row_gt, row_eq,
+                       tie_before, st, row_ptr, tie_take);
+    return check_launch("mtc_select_offsets");
+}
+
+extern "C" int mtc_select_fill(const mtc_desc* d, const void* acts, const mtc_select_state* st, const void* threshold,
+                               const int32_t* row_ptr, const uint32_t* tie_take, int32_t* col_idx, void* vals,
+                               void* stream) {
+    if (check_desc(d, "mtc_select_fill")) return -1;
+    MTC_REQUIRE(acts && st && row_ptr && tie_take && col_idx && vals, "mtc_select_fill: null pointer");
+    DISPATCH_DT(d->dtype, select_fill_kernel, dim3((d->B + 3) / 4), dim3(256), 0, as_stream(stream), acts, d->B, d->D,
+                st, threshold, row_ptr, tie_take, col_idx, vals);
+    return check_launch("mtc_select_fill");
+}
+
+extern "C" size_t mtc_select_workspace_bytes(const mtc_desc* d) {
+    if (!d) return 0;
+    return 3 * HIST_BINS * sizeof(uint32_t) + 3 * (size_t)((d->B + 63) & ~63) * sizeof(uint32_t);
+}
+
+extern "C" int mtc_select_global_topk(const mtc_desc* d, const void* acts, uint32_t k_total, const void* threshold,
+                                      void* workspace, size_t workspace_bytes, mtc_select_state* st, int32_t* row_ptr,
+                                      int32_t* col_idx, void* vals, void* stream) {
+    if (check_desc(d, "mtc_select_global_topk")) return -1;
+    MTC_REQUIRE(workspace && workspace_bytes >= mtc_select_workspace_bytes(d),
+                "mtc_select_global_topk: workspace too small (%zu < %zu)", workspace_bytes, mtc_select_workspace_bytes(d));
+    uint32_t* hist = reinterpret_cast<uint32_t*>(workspace);
+    const size_t bpad = (size_t)((d->B + 63) & ~63);
+    uint32_t* row_gt = hist + 3 * HIST_BINS;
+    uint32_t* row_eq = row_gt + bpad;
+    uint32_t* tie_take = row_eq + bpad;
+    int rc;
+    if ((rc = mtc_select_init(st, k_total, stream))) return rc;
+    if (!threshold) {
+        const int levels = mtc_select_levels(d);
+        if (hipMemsetAsync(hist, 0, 3 * HIST_BINS * sizeof(uint32_t), as_stream(stream)) != hipSuccess) {
+            set_error("mtc_select_global_topk: memset failed");
+            return -2;
+        }
+        for (int l = 0; l < levels; ++l) {
+            if ((rc = mtc_select_hist(d, acts, l, st, hist + l * HIST_BINS, stream))) return rc;
+            if ((rc = mtc_select_scan(d, l, hist + l * HIST_BINS, st, stream))) return rc;
+        }
+    }
+    if ((rc = mtc_select_count(d, acts, st, threshold, row_gt, row_eq, stream))) return rc;
+    if ((rc = mtc_select_offsets(d, row_gt, row_eq, nullptr, st, row_ptr, tie_take, stream))) return rc;
+    return mtc_select_fill(d, acts, st, threshold, row_ptr, tie_take, col_idx, vals, stream);
+}
+
+extern "C" int mtc_threshold_ema(const mtc_desc* d, const mtc_select_state* st, void* threshold, float lr, void* stream) {
+    if (check_desc(d, "mtc_threshold_ema")) return -1;
+    MTC_REQUIRE(st && threshold, "mtc_threshold_ema: null pointer");
+    DISPATCH_DT(d->dtype, threshold_ema_kernel, dim3(1), dim3(64), 0, as_stream(stream), st, threshold, lr);
+    return check_launch("mtc_threshold_ema");
+}
+
+extern "C" int mtc_densify(const mtc_desc* d, const int32_t* row_ptr, const int32_t* col_idx, const void* vals,
+                           int32_t max_col, void* dense, void* stream) {
+    if (check_desc(d, "mtc_densify")) return -1;
+    MTC_REQUIRE(row_ptr && col_idx && vals && dense, "mtc_densify: null pointer");
+    DISPATCH_DT(d->dtype, densify_kernel, dim3(d->B), dim3(256), 0, as_stream(stream), row_ptr, col_idx, vals, d->B, d->D,
+                max_col, dense);
+    return check_launch("mtc_densify");
+}

@@ -1,0 +1,249 @@
+"""Host-side sequencing of the HIP hot path (libmtc.so) on torch device tensors.
+
+PyTorch is plumbing here: it owns device memory (caching allocator) and the stream; every
+computation is a libmtc kernel launched on `torch.cuda.current_stream()`.  Nothing in this file
+synchronises the device except where the reference itself needs a host value.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import torch
+
+from . import _lib
+from ._lib import AdamHyper, check
+
+_CODES = {torch.float32: _lib.MTC_F32, torch.bfloat16: _lib.MTC_BF16}
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    try:
+        return _CODES[dt]
+    except KeyError:
+        raise _lib.MtcError(f"unsupported model dtype {dt}: libmtc computes in float32 or bfloat16") from None
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need(t: torch.Tensor, name: str, dt=None, shape=None):
+    if not t.is_cuda:
+        raise _lib.MtcError(f"{name} must live on the GPU (got {t.device}); there is no CPU path")
+    if not t.is_contiguous():
+        raise _lib.MtcError(f"{name} must be contiguous")
+    if dt is not None and t.dtype != dt:
+        raise _lib.MtcError(f"{name} must be {dt}, got {t.dtype}")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise _lib.MtcError(f"{name} must have shape {tuple(shape)}, got {tuple(t.shape)}")
+
+
+@dataclass
+class Selection:
+    """Row-major (CSR) selected activations of one batch + the feature-major (CSC) view of them."""
+    state: torch.Tensor            # int32[16]  (mtc_select_state)
+    row_ptr: torch.Tensor          # int32[B+1]
+    col_idx: torch.Tensor          # int32[cap]
+    vals: torch.Tensor             # dt[cap]
+    col_ptr: Optional[torch.Tensor] = None
+    csc_row: Optional[torch.Tensor] = None
+    csc_pos: Optional[torch.Tensor] = None
+
+
+@dataclass
+class ForwardResult:
+    B: int
+    desc: object
+    x_norm: torch.Tensor
+    mean: Optional[torch.Tensor]
+    std: Optional[torch.Tensor]
+    acts: Optional[torch.Tensor]
+    sel: Selection
+    x_hat: torch.Tensor
+    g: Optional[torch.Tensor]
+    d_vals: Optional[torch.Tensor]
+    row_stats: torch.Tensor
+    scalars: torch.Tensor          # float32[16], see mtc_reduce_scalars
+    recons: Optional[torch.Tensor] = None
+    aux: Optional[dict] = None
+    extra: dict = field(default_factory=dict)
+
+
+class HotPath:
+    """One instance per transcoder; stateless apart from the static problem description."""
+
+    def __init__(self, A_s: int, A_t: int, prefix: List[int], dtype: torch.dtype, unit_norm: bool):
+        self.lib = _lib.load()
+        self.A_s, self.A_t, self.prefix = int(A_s), int(A_t), [int(p) for p in prefix]
+        self.D = self.prefix[-1]
+        self.dtype = dtype
+        self.code = dtype_code(dtype)
+        self.unit_norm = bool(unit_norm)
+
+    def desc(self, B: int):
+        return _lib.make_desc(B, self.A_s, self.A_t, self.D, self.prefix, self.code, self.unit_norm)
+
+    # ------------------------------------------------------------------ a2
+    def normalize(self, d, x):
+        B = d.B
+        xn = torch.empty_like(x)
+        mean = torch.empty(B, dtype=self.dtype, device=x.device)
+        std = torch.empty(B, dtype=self.dtype, device=x.device)
+        check(self.lib.mtc_row_normalize(C.byref(d), _p(x), _p(xn), _p(mean), _p(std), _stream()), "mtc_row_normalize")
+        return xn, mean, std
+
+    # ------------------------------------------------------------------ a3 dense part
+    def encode(self, d, x_norm, W_encT, b_enc):
+        _need(W_encT, "W_encT", self.dtype, (self.D, self.A_s))
+        _need(b_enc, "b_enc", self.dtype, (self.D,))
+        acts = torch.empty(d.B, self.D, dtype=self.dtype, device=x_norm.device)
+        check(self.lib.mtc_encode_fwd(C.byref(d), _p(x_norm), _p(W_encT), _p(b_enc), _p(acts), _stream()), "mtc_encode_fwd")
+        return acts
+
+    # ------------------------------------------------------------------ a3 select / a4 threshold
+    def select_topk(self, d, acts, k_total: int) -> Selection:
+        dev = acts.device
+        ws_bytes = self.lib.mtc_select_workspace_bytes(C.byref(d))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        st = torch.empty(16, dtype=torch.int32, device=dev)
+        row_ptr = torch.empty(d.B + 1, dtype=torch.int32, device=dev)
+        cap = max(int(k_total), 1)
+        col_idx = torch.empty(cap, dtype=torch.int32, device=dev)
+        vals = torch.empty(cap, dtype=self.dtype, device=dev)
+        check(self.lib.mtc_select_global_topk(C.byref(d), _p(acts), int(k_total), None, _p(ws), ws_bytes, _p(st),
+                                              _p(row_ptr), _p(col_idx), _p(vals), _stream()), "mtc_select_global_topk")
+        return Selection(st, row_ptr, col_idx, vals)
+
+    def select_threshold(self, d, acts, threshold) -> Selection:
+        """Eval mode (sae.py:189-191).  The number of survivors is data dependent, so this path reads one
+        integer back to size the output (inference only; the training path never synchronises)."""
+        dev = acts.device
+        lib = self.lib
+        st = torch.empty(16, dtype=torch.int32, device=dev)
+        row_ptr = torch.empty(d.B + 1, dtype=torch.int32, device=dev)
+        row_gt = torch.empty(d.B, dtype=torch.int32, device=dev)
+        row_eq = torch.empty(d.B, dtype=torch.int32, device=dev)
+        tie_take = torch.empty(d.B, dtype=torch.int32, device=dev)
+        thr = threshold.reshape(1).to(self.dtype).contiguous()
+        s = _stream()
+        check(lib.mtc_select_init(_p(st), 0, s), "mtc_select_init")
+        check(lib.mtc_select_count(C.byref(d), _p(acts), _p(st), _p(thr), _p(row_gt), _p(row_eq), s), "mtc_select_count")
+        check(lib.mtc_select_offsets(C.byref(d), _p(row_gt), _p(row_eq), None, _p(st), _p(row_ptr), _p(tie_take), s),
+              "mtc_select_offsets")
+        nnz = int(row_ptr[-1].item())
+        col_idx = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
+        vals = torch.empty(max(nnz, 1), dtype=self.dtype, device=dev)
+        check(lib.mtc_select_fill(C.byref(d), _p(acts), _p(st), _p(thr), _p(row_ptr), _p(tie_take), _p(col_idx),
+                                  _p(vals), s), "mtc_select_fill")
+        return Selection(st, row_ptr, col_idx, vals)
+
+    def threshold_ema(self, d, sel: Selection, threshold: torch.Tensor, lr: float = 0.01):
+        _need(threshold, "threshold", self.dtype)
+        check(self.lib.mtc_threshold_ema(C.byref(d), _p(sel.state), _p(threshold), float(lr), _stream()), "mtc_threshold_ema")
+
+    # ------------------------------------------------------------------ a7 + CSC
+    def build_csc(self, d, sel: Selection, dead_cnt: Optional[torch.Tensor]):
+        dev = sel.row_ptr.device
+        ws_bytes = self.lib.mtc_csc_workspace_bytes(C.byref(d))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        cap = sel.col_idx.numel()
+        sel.col_ptr = torch.empty(self.D + 1, dtype=torch.int32, device=dev)
+        sel.csc_row = torch.empty(cap, dtype=torch.int32, device=dev)
+        sel.csc_pos = torch.empty(cap, dtype=torch.int32, device=dev)
+        if dead_cnt is not None:
+            _need(dead_cnt, "num_batches_not_active", torch.float32, (self.D,))
+        check(self.lib.mtc_build_csc(C.byref(d), _p(sel.row_ptr), _p(sel.col_idx), _p(ws), ws_bytes, _p(sel.col_ptr),
+                                     _p(sel.csc_row), _p(sel.csc_pos), _p(dead_cnt), _stream()), "mtc_build_csc")
+
+    # ------------------------------------------------------------------ a6 / a8 / a10
+    def decode(self, d, sel: Selection, W_dec, b_dec, x_target, mean, std, *, want_g: bool, want_dvals: bool,
+               l1_term: float = 0.0, want_recons: bool = False):
+        _need(W_dec, "W_dec", self.dtype, (self.D, self.A_t))
+        _need(b_dec, "b_dec", self.dtype, (self.A_t,))
+        _need(x_target, "x_target", self.dtype, (d.B, self.A_t))
+        dev = x_target.device
+        x_hat = torch.empty(d.B, self.A_t, dtype=self.dtype, device=dev)
+        g = torch.empty(d.B, self.A_t, dtype=torch.float32, device=dev) if want_g else None
+        row_stats = torch.empty(d.G + 4, d.B, dtype=torch.float32, device=dev)
+        recons = torch.empty(d.G, d.B, self.A_t, dtype=self.dtype, device=dev) if want_recons else None
+        d_vals = torch.empty(sel.col_idx.numel(), dtype=torch.float32, device=dev) if want_dvals else None
+        check(self.lib.mtc_decode_fwd(C.byref(d), _p(sel.row_ptr), _p(sel.col_idx), _p(sel.vals), _p(W_dec), _p(b_dec),
+                                      _p(x_target), _p(mean), _p(std), _p(x_hat), _p(g), _p(row_stats), _p(recons),
+                                      _p(d_vals), float(l1_term), _stream()), "mtc_decode_fwd")
+        return x_hat, g, row_stats, recons, d_vals
+
+    def decode_bwd_vals(self, d, sel: Selection, W_dec, g, l1_term: float):
+        d_vals = torch.empty(sel.col_idx.numel(), dtype=torch.float32, device=g.device)
+        check(self.lib.mtc_decode_bwd_vals(C.byref(d), _p(sel.row_ptr), _p(sel.col_idx), _p(W_dec), _p(g), float(l1_term),
+                                           _p(d_vals), _stream()), "mtc_decode_bwd_vals")
+        return d_vals
+
+    def reduce_scalars(self, d, row_stats, sel: Selection, n_feat_total: int, l1_coeff: float, aux_penalty: float,
+                       aux_rows=None, nnz_abs_override=None):
+        scalars = torch.empty(16, dtype=torch.float32, device=row_stats.device)
+        check(self.lib.mtc_reduce_scalars(C.byref(d), _p(row_stats), _p(aux_rows), _p(sel.state), _p(nnz_abs_override),
+                                          int(n_feat_total), float(l1_coeff), float(aux_penalty), _p(scalars), _stream()),
+              "mtc_reduce_scalars")
+        return scalars
+
+    # ------------------------------------------------------------------ a11
+    def backward(self, d, sel: Selection, g, d_vals, x_norm, scale: Optional[torch.Tensor], grads=None):
+        """Dense gradients (model dtype) for W_dec [D,A_t], W_encT [D,A_s], b_enc [D], b_dec [A_t]."""
+        dev = g.device
+        if grads is None:
+            dW_dec = torch.empty(self.D, self.A_t, dtype=self.dtype, device=dev)
+            dW_encT = torch.empty(self.D, self.A_s, dtype=self.dtype, device=dev)
+            db_enc = torch.empty(self.D, dtype=self.dtype, device=dev)
+            db_dec = torch.empty(self.A_t, dtype=self.dtype, device=dev)
+            acc = 0
+        else:
+            dW_dec, dW_encT, db_enc, db_dec = grads
+            acc = 1
+        if scale is not None:
+            scale = scale.reshape(1).to(torch.float32).contiguous()
+        check(self.lib.mtc_backward_sparse(C.byref(d), _p(sel.col_ptr), _p(sel.csc_row), _p(sel.csc_pos), _p(sel.vals),
+                                           _p(d_vals), _p(g), _p(x_norm), _p(scale), _p(dW_dec), _p(dW_encT), _p(db_enc),
+                                           acc, _stream()), "mtc_backward_sparse")
+        ws_bytes = self.lib.mtc_colsum_workspace_bytes(C.byref(d))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        check(self.lib.mtc_colsum(C.byref(d), _p(g), _p(scale), _p(ws), ws_bytes, _p(db_dec), acc, _stream()), "mtc_colsum")
+        return dW_dec, dW_encT, db_enc, db_dec
+
+    # ------------------------------------------------------------------ a12 / a13
+    def unitnorm_project(self, W_dec, grad):
+        _need(W_dec, "W_dec", self.dtype, (self.D, self.A_t))
+        _need(grad, "W_dec.grad", self.dtype, (self.D, self.A_t))
+        d = self.desc(1)
+        check(self.lib.mtc_unitnorm_project(C.byref(d), _p(W_dec), _p(grad), _stream()), "mtc_unitnorm_project")
+
+    def unitnorm_adam(self, W_dec, grad, m, v, hyper: AdamHyper, write_grad: bool = True):
+        for t, n in ((W_dec, "W_dec"), (grad, "W_dec.grad"), (m, "exp_avg"), (v, "exp_avg_sq")):
+            _need(t, n, self.dtype, (self.D, self.A_t))
+        d = self.desc(1)
+        check(self.lib.mtc_unitnorm_adam_rows(C.byref(d), _p(W_dec), _p(grad), _p(m), _p(v), C.byref(hyper),
+                                              int(write_grad), _stream()), "mtc_unitnorm_adam_rows")
+
+    def adam_flat(self, p, grad, m, v, hyper: AdamHyper):
+        for t, n in ((p, "param"), (grad, "grad"), (m, "exp_avg"), (v, "exp_avg_sq")):
+            _need(t, n, self.dtype)
+        check(self.lib.mtc_adam_flat(self.code, p.numel(), _p(p), _p(grad), _p(m), _p(v), C.byref(hyper), _stream()),
+              "mtc_adam_flat")
+
+    # ------------------------------------------------------------------ a15
+    def densify(self, d, sel: Selection, max_col: int):
+        dense = torch.empty(d.B, self.D, dtype=self.dtype, device=sel.row_ptr.device)
+        check(self.lib.mtc_densify(C.byref(d), _p(sel.row_ptr), _p(sel.col_idx), _p(sel.vals), int(max_col), _p(dense),
+                                   _stream()), "mtc_densify")
+        return dense
+
+
+def adam_hyper(lr, beta1, beta2, eps, step) -> AdamHyper:
+    h = AdamHyper()
+    h.lr, h.beta1, h.beta2, h.eps, h.step, h.pad = float(lr), float(beta1), float(beta2), float(eps), int(step), 0
+    return h

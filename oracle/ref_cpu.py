@@ -177,7 +177,7 @@ def fvu_from_sse(sse: torch.Tensor, n_elem: int, var_target: torch.Tensor) -> to
 
 
 # --------------------------------------------------------------------------- forward (sae.py:195-269)
-def forward(params, state, x_source, x_target, cfg, training: bool = True, want_grads: bool = True):
+def forward(params, state, x_source, x_target, cfg, training: bool = True, acts_override=None):
     """One forward of the transcoder in sparse form.  Mutates nothing; returns
 
       out    : the reference's 11-key dict (sae.py:257-269)
@@ -194,6 +194,8 @@ def forward(params, state, x_source, x_target, cfg, training: bool = True, want_
 
     xn, mean, std = preprocess(x_source, unit)
     acts = encode_acts(xn, params["W_enc"], params["b_enc"])                      # [B, D] dt
+    if acts_override is not None:       # tests: decouple the select/decode checks from GEMM rounding
+        acts = acts_override
 
     new_threshold = params["threshold"]
     if training:

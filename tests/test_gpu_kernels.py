@@ -1,0 +1,235 @@
+"""GPU parity: every libmtc kernel (through the C ABI) against the CPU oracle on the same inputs.
+Bar: indices bit-exact given identical activations; floating point within the tolerances in the
+asserts (fp32 rel 1e-4, bf16 rel 2e-2 / 1 ulp)."""
+import pytest
+import torch
+
+from conftest import SMALL_CASES, load_golden
+from oracle import ref_cpu as R
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _hot(cfg):
+    from matryoshka_transcoder_amd.engine import HotPath
+    a_s = cfg.get("source_act_size", cfg["act_size"])
+    a_t = cfg.get("target_act_size", cfg["act_size"])
+    return HotPath(a_s, a_t, cfg["prefix_sizes"], cfg["dtype"], cfg.get("input_unit_norm", False))
+
+
+def _close(a, b, rtol, atol, msg=""):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    assert a.shape == b.shape, (msg, a.shape, b.shape)
+    err = (a - b).abs()
+    ok = err <= atol + rtol * b.abs()
+    assert bool(ok.all()), f"{msg}: {int((~ok).sum())} of {ok.numel()} off, max abs {err.max():.3e}"
+
+
+def run_forward(hp, cfg, params, cnt, xs, xt, want_recons=True):
+    """The single-GPU kernel chain for one training forward + backward (no aux)."""
+    dev = DEV
+    B = xs.shape[0]
+    d = hp.desc(B)
+    W_encT = params["W_enc"].t().contiguous().to(dev)
+    b_enc, W_dec, b_dec = (params[k].to(dev) for k in ("b_enc", "W_dec", "b_dec"))
+    thr = params["threshold"].clone().to(dev)
+    x, t = xs.to(dev), xt.to(dev)
+    if hp.unit_norm:
+        xn, mean, std = hp.normalize(d, x)
+    else:
+        xn, mean, std = x, None, None
+    acts = hp.encode(d, xn, W_encT, b_enc)
+    sel = hp.select_topk(d, acts, cfg["top_k"] * B)
+    hp.threshold_ema(d, sel, thr)
+    cnt_dev = cnt.clone().to(dev)
+    hp.build_csc(d, sel, cnt_dev)
+    l1_term = cfg["l1_coeff"] / (B * hp.D)
+    x_hat, g, row_stats, recons, d_vals = hp.decode(d, sel, W_dec, b_dec, t, mean, std, want_g=True, want_dvals=True,
+                                                    l1_term=l1_term, want_recons=want_recons)
+    scalars = hp.reduce_scalars(d, row_stats, sel, hp.D, cfg["l1_coeff"], cfg["aux_penalty"])
+    grads = hp.backward(d, sel, g, d_vals, xn, None)
+    torch.cuda.synchronize()
+    return dict(xn=xn, mean=mean, std=std, acts=acts, sel=sel, thr=thr, cnt=cnt_dev, x_hat=x_hat, g=g,
+                row_stats=row_stats, recons=recons, d_vals=d_vals, scalars=scalars, grads=grads)
+
+
+def check_against_oracle(cfg, params, cnt, xs, xt, res, hp):
+    dt = cfg["dtype"]
+    f32 = dt == torch.float32
+    B = xs.shape[0]
+    D = hp.D
+    acts_gpu = res["acts"].cpu()
+    out, new, inter = R.forward(params, {"num_batches_not_active": cnt.clone()}, xs, xt, cfg, acts_override=acts_gpu)
+    o_free, _, i_free = R.forward(params, {"num_batches_not_active": cnt.clone()}, xs, xt, cfg)
+    # a2
+    if hp.unit_norm:
+        _close(res["xn"], inter["x_norm"], 0, 1e-6 if f32 else 0, "x_norm") if f32 else \
+            _close(res["xn"], inter["x_norm"], 8e-3, 1e-6, "x_norm")
+        _close(res["mean"], inter["mean"].flatten(), 1e-5 if f32 else 8e-3, 1e-6, "mean")
+        _close(res["std"], inter["std"].flatten(), 1e-5 if f32 else 8e-3, 1e-6, "std")
+    # a3 dense part: GEMM vs the oracle's own fp32 contraction (different summation order)
+    _close(acts_gpu, i_free["acts"], 1e-5 if f32 else 8e-3, 1e-5 if f32 else 1e-3, "acts")
+    # a3 select: BIT-EXACT indices and values given identical activations
+    sel = res["sel"]
+    st = sel.state.cpu()
+    nnz = int(st[7])
+    rp = sel.row_ptr.cpu()
+    assert int(rp[-1]) == nnz == inter["flat_idx"].numel()
+    cols = sel.col_idx.cpu()[:nnz].long()
+    rows = torch.repeat_interleave(torch.arange(B), (rp[1:] - rp[:-1]).long())
+    flat = rows * D + cols
+    assert torch.equal(flat, inter["flat_idx"]), "selected flat indices differ from the oracle's"
+    assert torch.equal(sel.vals.cpu()[:nnz], inter["vals"])
+    assert torch.equal(rp, inter["row_ptr"])
+    tau_bits = int(st[4]) & 0xffffffff
+    assert tau_bits == int(inter["tau"].float().view(torch.int32)) & 0xffffffff
+    assert int(st[3]) == inter["n_gt"] and int(st[5]) == inter["n_tie"]
+    # a5
+    _close(res["thr"], new["threshold"], 1e-6 if f32 else 8e-3, 0, "threshold")
+    # a7
+    assert torch.equal(res["cnt"].cpu(), new["num_batches_not_active"])
+    # CSC is a permutation of CSR, sorted by (feature, row)
+    cp = sel.col_ptr.cpu().long()
+    assert int(cp[-1]) == nnz
+    crow, cpos = sel.csc_row.cpu()[:nnz].long(), sel.csc_pos.cpu()[:nnz].long()
+    assert torch.equal(torch.sort(cpos).values, torch.arange(nnz))
+    feat = torch.repeat_interleave(torch.arange(D), cp[1:] - cp[:-1])
+    assert torch.equal(cols[cpos], feat) and torch.equal(rows[cpos], crow)
+    key = feat * B + crow
+    assert bool((key[1:] > key[:-1]).all()), "CSC must be ordered by (feature, batch row)"
+    # a6 / a10
+    for i in range(len(cfg["prefix_sizes"])):
+        _close(res["recons"][i], inter["recons"][i], 1e-5 if f32 else 8e-3, 1e-5 if f32 else 2e-3, f"recon {i}")
+    _close(res["x_hat"], inter["recons"][-1], 1e-5 if f32 else 8e-3, 1e-5 if f32 else 2e-3, "x_hat")
+    G = len(cfg["prefix_sizes"])
+    _close(res["row_stats"][:G].sum(1), inter["sse"], 1e-4 if f32 else 2e-2, 1e-6, "sse")
+    s = res["scalars"].cpu()
+    names = {"l2_loss": 0, "l1_loss": 1, "l0_norm": 2, "l1_norm": 3, "aux_loss": 4, "loss": 5, "fvu": 6, "fvu_min": 7,
+             "fvu_max": 8, "fvu_mean": 9}
+    for k, i in names.items():
+        _close(s[i], out[k].float(), 1e-4 if f32 else 2e-2, 1e-6, k)
+    _close(s[10], inter["var_target"], 1e-5, 1e-7, "var(x_t)")
+    # a11
+    grads = R.backward(params, xs, xt, cfg, inter)
+    _close(res["g"], grads["g"], 1e-4 if f32 else 2e-2, 1e-7 if f32 else 1e-5, "g")
+    _close(res["d_vals"][:nnz], grads["d_vals"], 1e-4 if f32 else 2e-2, 1e-7 if f32 else 1e-5, "d_vals")
+    dW_dec, dW_encT, db_enc, db_dec = res["grads"]
+    rt, at = (1e-4, 1e-7) if f32 else (2e-2, 2e-5)
+    _close(dW_dec, grads["W_dec"], rt, at, "dW_dec")
+    _close(dW_encT.t(), grads["W_enc"], rt, at, "dW_enc")
+    _close(db_enc, grads["b_enc"], rt, at, "db_enc")
+    _close(db_dec, grads["b_dec"], rt, at * 10, "db_dec")
+    if f32:
+        assert torch.equal(dW_dec.cpu() != 0, grads["W_dec"] != 0)
+    return out, inter
+
+
+@pytest.mark.parametrize("name", [c for c in SMALL_CASES if "aux" not in c])
+def test_small_golden_shapes(name, gpu_lib):
+    fx, cfg = load_golden(name)
+    hp = _hot(cfg)
+    params = {k: v.clone() for k, v in fx["init"].items()}
+    s0 = fx["steps"][0]
+    res = run_forward(hp, cfg, params, fx["cnt0"], s0["x_source"], s0["x_target"])
+    check_against_oracle(cfg, params, fx["cnt0"], s0["x_source"], s0["x_target"], res, hp)
+    # and against the reference's own numbers from the fixture
+    s = res["scalars"].cpu()
+    f32 = cfg["dtype"] == torch.float32
+    for k, i in {"l2_loss": 0, "l0_norm": 2, "fvu": 6, "fvu_mean": 9}.items():
+        _close(s[i], s0["out"][k].float(), 1e-4 if f32 else 2e-2, 1e-6, f"{k} vs reference fixture")
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("unit", [False, True])
+def test_mid_shape_mfma_path(dt, unit, gpu_lib):
+    """A=768 (multiple of 64 -> MFMA encoder for bf16), D=12288, GPT-2 prefixes, B=192 (ragged tiles)."""
+    cfg = dict(seed=49, prefix_sizes=[768, 2304, 5376, 12288], act_size=768, top_k=64, top_k_aux=512,
+               aux_penalty=1 / 32, n_batches_to_dead=20, l1_coeff=0.0 if unit else 1e-3, dtype=dt, device="cpu",
+               input_unit_norm=unit, lr=3e-4, beta1=0.9, beta2=0.99)
+    B = 192
+    params = R.init_params(cfg)
+    params["b_enc"] = (0.01 * torch.randn(12288, generator=torch.Generator().manual_seed(3))).to(dt)
+    params["b_dec"] = (0.01 * torch.randn(768, generator=torch.Generator().manual_seed(4))).to(dt)
+    g = torch.Generator("cpu").manual_seed(1000)
+    xs = torch.randn(B, 768, generator=g).to(dt)
+    xt = torch.randn(B, 768, generator=g).to(dt)
+    hp = _hot(cfg)
+    cnt = torch.zeros(12288)
+    res = run_forward(hp, cfg, params, cnt, xs, xt)
+    check_against_oracle(cfg, params, cnt, xs, xt, res, hp)
+
+
+def test_fewer_positives_than_k(gpu_lib):
+    """Edge: fewer than k*B positive activations -> every positive is selected, zeros never are."""
+    cfg = dict(seed=1, prefix_sizes=[16, 48, 112, 256], act_size=32, top_k=200, top_k_aux=8, aux_penalty=1 / 32,
+               n_batches_to_dead=20, l1_coeff=0.0, dtype=torch.float32, device="cpu", input_unit_norm=False)
+    params = R.init_params(cfg)
+    params["b_enc"] = torch.full((256,), -0.5)
+    g = torch.Generator("cpu").manual_seed(5)
+    xs, xt = torch.randn(16, 32, generator=g), torch.randn(16, 32, generator=g)
+    hp = _hot(cfg)
+    cnt = torch.zeros(256)
+    res = run_forward(hp, cfg, params, cnt, xs, xt)
+    out, inter = check_against_oracle(cfg, params, cnt, xs, xt, res, hp)
+    assert inter["flat_idx"].numel() < 200 * 16
+    assert int(res["sel"].state.cpu()[2]) == 1      # all_pos
+
+
+def test_heavy_ties_bf16(gpu_lib):
+    """Edge: thousands of activations equal to tau (bf16) -> ties taken in ascending flat index order."""
+    cfg = dict(seed=2, prefix_sizes=[64, 128, 256, 512], act_size=64, top_k=8, top_k_aux=8, aux_penalty=1 / 32,
+               n_batches_to_dead=20, l1_coeff=0.0, dtype=torch.bfloat16, device="cpu", input_unit_norm=False)
+    params = R.init_params(cfg)
+    g = torch.Generator("cpu").manual_seed(6)
+    # inputs on a coarse grid so that many pre-activations collide exactly
+    xs = (torch.randint(-2, 3, (128, 64), generator=g).float() * 0.5).to(torch.bfloat16)
+    params["W_enc"] = (torch.randint(-2, 3, (64, 512), generator=g).float() * 0.125).to(torch.bfloat16)
+    xt = torch.randn(128, 64, generator=g).to(torch.bfloat16)
+    hp = _hot(cfg)
+    cnt = torch.zeros(512)
+    res = run_forward(hp, cfg, params, cnt, xs, xt)
+    out, inter = check_against_oracle(cfg, params, cnt, xs, xt, res, hp)
+    acts = res["acts"].cpu().float().flatten()
+    n_eq = int((acts == inter["tau"].float()).sum())
+    assert n_eq > inter["n_tie"] > 0, (n_eq, inter["n_tie"])
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_unitnorm_adam_against_oracle(dt, gpu_lib):
+    from matryoshka_transcoder_amd.engine import HotPath, adam_hyper
+    D, A = 512, 96
+    hp = HotPath(A, A, [128, 512], dt, False)
+    gen = torch.Generator().manual_seed(11)
+    W = torch.randn(D, A, generator=gen).to(dt)
+    m = (0.01 * torch.randn(D, A, generator=gen)).to(dt)
+    v = (1e-4 * torch.rand(D, A, generator=gen)).to(dt)
+    grad = (0.01 * torch.randn(D, A, generator=gen)).to(dt)
+    grad[5] = 0
+    Wn, gp = R.unit_norm_project(W, grad)
+    step = 3
+    p_ref, m_ref, v_ref = R.adam_step(Wn, gp, m, v, step, 3e-4, 0.9, 0.99)
+    Wd, gd, md, vd = (t.clone().to(DEV) for t in (W, grad, m, v))
+    hp.unitnorm_adam(Wd, gd, md, vd, adam_hyper(3e-4, 0.9, 0.99, 1e-8, step))
+    # projection alone
+    W2, g2 = W.clone().to(DEV), grad.clone().to(DEV)
+    hp.unitnorm_project(W2, g2)
+    torch.cuda.synchronize()
+    rt, at = (1e-5, 1e-7) if dt == torch.float32 else (8e-3, 1e-4)
+    _close(W2, Wn, rt, at, "normed")
+    _close(g2, gp, rt * 4, at, "projected grad")
+    _close(gd, gp, rt * 4, at, "projected grad (fused)")
+    _close(md, m_ref, rt * 2, at, "exp_avg")
+    _close(vd, v_ref, rt * 2, at * 1e-2, "exp_avg_sq")
+    _close(Wd, p_ref, rt * 2, at, "W after step")
+    # flat Adam
+    n = 4096
+    p = torch.randn(n, generator=gen).to(dt)
+    gflat = (0.01 * torch.randn(n, generator=gen)).to(dt)
+    m0 = torch.zeros(n).to(dt); v0 = torch.zeros(n).to(dt)
+    pr, mr, vr = R.adam_step(p, gflat, m0, v0, 1, 3e-4, 0.9, 0.99)
+    pd, gdv, mdv, vdv = (t.clone().to(DEV) for t in (p, gflat, m0, v0))
+    hp.adam_flat(pd, gdv, mdv, vdv, adam_hyper(3e-4, 0.9, 0.99, 1e-8, 1))
+    torch.cuda.synchronize()
+    _close(pd, pr, rt, at, "flat p"); _close(mdv, mr, rt * 2, at, "flat m"); _close(vdv, vr, rt * 2, at * 1e-2, "flat v")
