@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""Headline benchmark: train tokens/s (forward + backward + unit-norm projection + Adam) of the
+Matryoshka transcoder at BASELINE.json's Gemma-2-2B shapes (A 2304, D 36864, k 96, B 4096,
+cumulative prefixes [2304, 6912, 16128, 36864]) on synthetic Gaussian activations.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|fp32] [--workload gemma2-2b|gpt2]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line (rank 0).  N > 1 shards the dictionary by features over the ranks (same
+global batch: strong scaling) with RCCL collectives through torch.distributed.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (A, group sizes as BASELINE.json lists them, top_k, batch)
+    "gemma2-2b": (2304, [2304, 4608, 9216, 20736], 96, 4096),
+    "gpt2": (768, [768, 1536, 3072, 6912], 64, 1024),
+}
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+MFMA_BF16_PEAK_TF = 2500.0     # dense bf16
+MFMA_F32_PEAK_TF = 157.3
+
+
+def cumulative(groups):
+    out, run = [], 0
+    for g in groups:
+        run += g
+        out.append(run)
+    return out
+
+
+def make_cfg(workload, dtype, device, unit_norm=False):
+    A, groups, k, B = WORKLOADS[workload]
+    prefix = cumulative(groups)
+    return dict(seed=49, prefix_sizes=prefix, act_size=A, dict_size=prefix[-1], top_k=k, top_k_aux=512,
+                aux_penalty=1 / 32, n_batches_to_dead=20, l1_coeff=0.0, dtype=dtype, device=device,
+                input_unit_norm=unit_norm, lr=3e-4, beta1=0.9, beta2=0.99, batch_size=B), B
+
+
+def batch_pool(B, A, dtype, device, n=8):
+    pool = []
+    for i in range(n):
+        g = torch.Generator("cpu").manual_seed(1000 + i)
+        xs = torch.randn(B, A, generator=g).to(dtype)
+        xt = torch.randn(B, A, generator=g).to(dtype)
+        pool.append((xs.to(device), xt.to(device)))
+    return pool
+
+
+def cpu_baseline(workload, dtype, budget_rows=512, steps=2):
+    """Reference algorithm on the host cores: oracle.DenseStep (same ATen call sequence as the
+    reference's step), on a bounded sample = `steps` steps at B=budget_rows of the same shapes."""
+    from oracle import ref_cpu as R
+    cores = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    cfg, _ = make_cfg(workload, dtype, "cpu")
+    A = cfg["act_size"]
+    model = R.DenseStep(cfg)
+    pool = batch_pool(budget_rows, A, dtype, "cpu", n=2)
+    model.step(*pool[0])                      # warm-up
+    t0 = time.perf_counter()
+    for i in range(steps):
+        model.step(*pool[i % 2])
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": budget_rows / dt, "unit": "tokens/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} steps at B={budget_rows} rows of the {workload} shapes (D={cfg['prefix_sizes'][-1]}, "
+                      f"k={cfg['top_k']}), {str(dtype).split('.')[-1]}, torch {torch.__version__} CPU, "
+                      f"oracle.DenseStep (dense eager port of the reference step)"}
+
+
+def stage_times(tc, opt, pool, reps=5):
+    """Per-stage device time of one step, HIP events on the launch stream (torch's current stream)."""
+    from matryoshka_transcoder_amd import engine
+    hp = tc.hot_path()
+    names, evs = [], []
+    orig = {}
+
+    def wrap(name):
+        fn = getattr(hp, name)
+        orig[name] = fn
+
+        def inner(*a, **k):
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(*a, **k)
+            e1.record()
+            names.append(name); evs.append((e0, e1))
+            return r
+        setattr(hp, name, inner)
+
+    for n in ("normalize", "encode", "select_topk", "threshold_ema", "build_csc", "decode", "reduce_scalars",
+              "backward", "unitnorm_adam", "adam_flat"):
+        wrap(n)
+    acc = {}
+    for r in range(reps):
+        names.clear(); evs.clear()
+        xs, xt = pool[r % len(pool)]
+        out = tc(xs, xt)
+        out["loss"].backward()
+        opt.step(project=True)
+        opt.zero_grad()
+        torch.cuda.synchronize()
+        for n, (e0, e1) in zip(names, evs):
+            acc.setdefault(n, []).append(e0.elapsed_time(e1))
+    for n, fn in orig.items():
+        setattr(hp, n, fn)
+    out = {}
+    # several calls of one stage inside a step (adam_flat x3) are summed per step
+    for n, v in acc.items():
+        per_step = len(v) // reps
+        out[n] = sum(sorted(v)[: len(v)]) / reps if per_step else 0.0
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--workload", default="gemma2-2b", choices=list(WORKLOADS))
+    ap.add_argument("--unit-norm", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    torch.cuda.set_device(local_rank)
+    device = f"cuda:{local_rank}"
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device(device))
+
+    cfg, B = make_cfg(args.workload, dtype, device, args.unit_norm)
+    A, D, k = cfg["act_size"], cfg["prefix_sizes"][-1], cfg["top_k"]
+    if world > 1:
+        from matryoshka_transcoder_amd.sharded import ShardedMatryoshkaTranscoder, ShardedFusedAdam
+        tc = ShardedMatryoshkaTranscoder(cfg)
+        opt = ShardedFusedAdam(tc, lr=cfg["lr"], betas=(cfg["beta1"], cfg["beta2"]))
+    else:
+        from matryoshka_transcoder_amd.transcoder import MatryoshkaTranscoder
+        from matryoshka_transcoder_amd.training import FusedAdam
+        tc = MatryoshkaTranscoder(cfg)
+        opt = FusedAdam(tc, lr=cfg["lr"], betas=(cfg["beta1"], cfg["beta2"]))
+    pool = batch_pool(B, A, dtype, device)
+
+    def step(i):
+        xs, xt = pool[i % len(pool)]
+        out = tc(xs, xt)
+        out["loss"].backward()
+        opt.step(project=True)
+        opt.zero_grad()
+        return out
+
+    def fence():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms = elapsed / args.steps * 1e3
+    value = B * args.steps / elapsed
+
+    result = {
+        "metric": "train tokens/sec (fwd+bwd+Adam), Gemma-2-2B d=36864 k=96" if args.workload == "gemma2-2b"
+        else "train tokens/sec (fwd+bwd+Adam), GPT-2 small d=12288 k=64",
+        "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"{args.workload}: act {A}, dict {D}, cumulative prefixes {cfg['prefix_sizes']}, "
+                               f"top_k {k}, batch {B}, input_unit_norm {args.unit_norm}",
+                   "global_batch": B, "parallelism": "single GPU" if world == 1 else f"dictionary sharded x{world}",
+                   "final_loss": float(out["loss"].detach().float()), "final_l0": float(out["l0_norm"].detach())},
+    }
+    if rank == 0 and world == 1:
+        st = stage_times(tc, opt, pool)
+        s = 2 if dtype == torch.bfloat16 else 4
+        nnz = k * B
+        flop_enc = 2.0 * B * A * D
+        # algorithmic bytes per launch (DESIGN.md "Kernels"): SURVEY 8(d) per-unit figures x units per launch
+        algo = {
+            "encode": ("mfma", flop_enc),
+            "select_topk": ("hbm", B * D * s + nnz * 8),
+            "decode": ("hbm", 2 * nnz * A * s + nnz * 12 + 3 * B * A * s + B * A * 4),
+            "backward": ("hbm", nnz * (A * 4 + A * s) + 2 * D * A * s + B * A * 4),
+            "unitnorm_adam": ("hbm", D * A * 7 * s),
+            "adam_flat": ("hbm", (D * A + D + A) * 7 * s),
+        }
+        kernels = {}
+        for n, t_ms in st.items():
+            entry = {"ms": t_ms}
+            if n in algo:
+                kind, q = algo[n]
+                if kind == "mfma":
+                    peak = MFMA_BF16_PEAK_TF if dtype == torch.bfloat16 else MFMA_F32_PEAK_TF
+                    ach = q / (t_ms * 1e-3) / 1e12
+                    entry.update(bound="mfma", achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak)
+                else:
+                    ach = q / (t_ms * 1e-3) / 1e9
+                    entry.update(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS)
+            kernels[n] = entry
+        dom = max((n for n in kernels if "bound" in kernels[n]), key=lambda n: kernels[n]["ms"])
+        result["roofline"] = {"kernel": dom, **{k2: kernels[dom][k2] for k2 in ("bound", "achieved", "peak", "unit", "frac")},
+                              "traffic": None}
+        result["stages"] = kernels
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args.workload, dtype)
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -85,7 +85,8 @@ int mtc_select_hist(const mtc_desc* d, const void* acts, int level, const mtc_se
                     uint32_t* hist, void* stream);
 int mtc_select_scan(const mtc_desc* d, int level, const uint32_t* hist, mtc_select_state* st,
                     void* stream);
-/* per-row counts of values > tau and == tau (or, threshold mode, > *threshold: sae.py:189-191) */
+/* per-row counts of values > tau and == tau (or, threshold mode, > *threshold: sae.py:189-191;
+ * a NaN *threshold selects every non-zero entry: dense -> CSR for decode()) */
 int mtc_select_count(const mtc_desc* d, const void* acts, const mtc_select_state* st,
                      const void* threshold /* NULL in TopK mode; model-dtype scalar otherwise */,
                      uint32_t* row_gt, uint32_t* row_eq, void* stream);
@@ -116,7 +117,8 @@ int mtc_threshold_ema(const mtc_desc* d, const mtc_select_state* st, void* thres
  *   x_hat     [B][A_t] model dtype (last prefix)          row_stats [G+4][B] float:
  *   g         [B][A_t] float, = 2/(B*A_t) * (x_hat-x_t) * std_row    rows 0..G-1  SSE of prefix i
  *             (NULL = forward only)                                  row G sum x_t, G+1 sum x_t^2,
- *   recons    optional [G][B][A_t] model dtype (every prefix)        row G+2 sum |a|, G+3 unused */
+ *   recons    optional [G][B][A_t] model dtype (every prefix)        row G+2 sum |a|, G+3 unused
+ * Pure decode (a15, sae.py:389-406): x_target = g = row_stats = d_vals = NULL. */
 int mtc_decode_fwd(const mtc_desc* d, const int32_t* row_ptr, const int32_t* col_idx,
                    const void* vals, const void* W_dec, const void* b_dec, const void* x_target,
                    const void* mean, const void* std, void* x_hat, float* g, float* row_stats,

@@ -82,12 +82,13 @@ __device__ __forceinline__ float boundary_sse(const RowCtx<DT, NC>& rc, const De
                                               void* __restrict__ recon_out /* row base or null */) {
     typedef DType<DT> D_;
     float sse = 0.f;
+    if (!x_target && !recon_out) return 0.f;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         if (rc.valid(c)) {
-            float b[8], t[8], r[8];
+            float b[8], t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, r[8];
             load8<DT>(b_dec, rc.off(c), b);
-            load8<DT>(x_target, (size_t)row * p.A_t + rc.off(c), t);
+            if (x_target) load8<DT>(x_target, (size_t)row * p.A_t + rc.off(c), t);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 float v = D_::rnd(acc[c][k] + b[k]);
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(256) void decode_fwd_kernel(DecodeParams p, const i
             if (upto <= i) {
                 const float sse = boundary_sse<DT, NC>(rc, p, row, acc, b_dec, x_target, mean, stdv,
                     recons ? reinterpret_cast<T*>(recons) + ((size_t)gi * p.B + row) * p.A_t : nullptr);
-                if (rc.lane == 0) row_stats[(size_t)gi * p.B + row] = sse;
+                if (rc.lane == 0 && row_stats) row_stats[(size_t)gi * p.B + row] = sse;
                 ++gi;
                 continue;
             }
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(256) void decode_fwd_kernel(DecodeParams p, const i
     for (; gi < p.G - 1; ++gi) {
         const float sse = boundary_sse<DT, NC>(rc, p, row, acc, b_dec, x_target, mean, stdv,
             recons ? reinterpret_cast<T*>(recons) + ((size_t)gi * p.B + row) * p.A_t : nullptr);
-        if (rc.lane == 0) row_stats[(size_t)gi * p.B + row] = sse;
+        if (rc.lane == 0 && row_stats) row_stats[(size_t)gi * p.B + row] = sse;
     }
     // ---- last prefix: x_hat, sse, target moments, g
     float sse = 0.f, sx = 0.f, sxx = 0.f;
@@ -164,9 +165,9 @@ __global__ __launch_bounds__(256) void decode_fwd_kernel(DecodeParams p, const i
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         if (rc.valid(c)) {
-            float b[8], t[8], r[8], gg[8];
+            float b[8], t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, r[8], gg[8];
             load8<DT>(b_dec, rc.off(c), b);
-            load8<DT>(x_target, (size_t)row * p.A_t + rc.off(c), t);
+            if (x_target) load8<DT>(x_target, (size_t)row * p.A_t + rc.off(c), t);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 float v = D_::rnd(acc[c][k] + b[k]);
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(256) void decode_fwd_kernel(DecodeParams p, const i
         }
     }
     sse = wave_sum(sse); sx = wave_sum(sx); sxx = wave_sum(sxx); abs_sum = wave_sum(abs_sum);
-    if (rc.lane == 0) {
+    if (rc.lane == 0 && row_stats) {
         row_stats[(size_t)(p.G - 1) * p.B + row] = sse;
         row_stats[(size_t)(p.G + 0) * p.B + row] = sx;
         row_stats[(size_t)(p.G + 1) * p.B + row] = sxx;
@@ -426,8 +427,10 @@ extern "C" int mtc_decode_fwd(const mtc_desc* d, const int32_t* row_ptr, const i
                               const void* std, void* x_hat, float* g, float* row_stats, void* recons, float* d_vals,
                               float l1_term, void* stream) {
     if (check_desc(d, "mtc_decode_fwd")) return -1;
-    MTC_REQUIRE(row_ptr && col_idx && vals && W_dec && b_dec && x_target && x_hat && row_stats,
-                "mtc_decode_fwd: null pointer");
+    MTC_REQUIRE(row_ptr && col_idx && vals && W_dec && b_dec && x_hat, "mtc_decode_fwd: null pointer");
+    MTC_REQUIRE(x_target || (!g && !d_vals && !row_stats),
+                "mtc_decode_fwd: g / d_vals / row_stats need x_target (pure decode passes all four as NULL)");
+    MTC_REQUIRE(!x_target || row_stats, "mtc_decode_fwd: row_stats is required with x_target");
     MTC_REQUIRE(!d->unit_norm || (mean && std), "mtc_decode_fwd: unit_norm needs mean/std");
     const DecodeParams p = make_params(d, l1_term);
     DISPATCH_NC(d->dtype, nc_for(d->A_t), decode_fwd_kernel, dim3((d->B + 3) / 4), dim3(256), as_stream(stream), p,

@@ -123,9 +123,12 @@ __global__ __launch_bounds__(256) void select_count_kernel(const void* __restric
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= B) return;
-    float tau; bool ties = false;
-    if (threshold) tau = fmaxf(DType<DT>::ld(reinterpret_cast<const typename DType<DT>::T*>(threshold)), 0.f);
-    else if (st->all_pos) tau = 0.f;
+    float tau; bool ties = false, nz = false;
+    if (threshold) {
+        tau = DType<DT>::ld(reinterpret_cast<const typename DType<DT>::T*>(threshold));
+        nz = tau != tau;                      // NaN threshold = "every non-zero entry" (dense -> CSR)
+        tau = nz ? 0.f : fmaxf(tau, 0.f);
+    } else if (st->all_pos) tau = 0.f;
     else { tau = __uint_as_float(st->tau_bits); ties = true; }
     const size_t base = (size_t)row * D;
     uint32_t gt = 0, eq = 0, mn = 0xffffffffu;
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(256) void select_count_kernel(const void* __restric
         load8<DT>(acts, base + (size_t)c * 8, v);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            if (v[i] > tau) { ++gt; mn = min(mn, __float_as_uint(v[i])); }
+            if (nz ? (v[i] != 0.f) : (v[i] > tau)) { ++gt; mn = min(mn, __float_as_uint(v[i])); }
             else if (ties && v[i] == tau) ++eq;
         }
     }
@@ -216,9 +219,12 @@ __global__ __launch_bounds__(256) void select_fill_kernel(const void* __restrict
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= B) return;
-    float tau; uint32_t quota = 0;
-    if (threshold) tau = fmaxf(DType<DT>::ld(reinterpret_cast<const T*>(threshold)), 0.f);
-    else if (st->all_pos) tau = 0.f;
+    float tau; uint32_t quota = 0; bool nz = false;
+    if (threshold) {
+        tau = DType<DT>::ld(reinterpret_cast<const T*>(threshold));
+        nz = tau != tau;
+        tau = nz ? 0.f : fmaxf(tau, 0.f);
+    } else if (st->all_pos) tau = 0.f;
     else { tau = __uint_as_float(st->tau_bits); quota = tie_take[row]; }
     const size_t base = (size_t)row * D;
     uint32_t out = (uint32_t)row_ptr[row];
@@ -232,7 +238,7 @@ __global__ __launch_bounds__(256) void select_fill_kernel(const void* __restrict
             load8<DT>(acts, base + (size_t)c * 8, v);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                if (v[i] > tau) gtm |= 1u << i;
+                if (nz ? (v[i] != 0.f) : (v[i] > tau)) gtm |= 1u << i;
                 else if (quota && v[i] == tau) eqm |= 1u << i;
             }
         }

@@ -1,0 +1,156 @@
+"""Training loop, LR schedules and the fused optimizer (reference: src/training/training.py).
+
+`train_transcoder(transcoder, activation_store, model, cfg)` keeps the reference's signature and
+step order (forward -> backward -> decoder unit-norm projection -> Adam -> scheduler,
+training.py:87-183) but never synchronises the device inside the loop: metrics stay on the GPU
+and are read back only every `log_freq` steps and at checkpoints.
+"""
+from __future__ import annotations
+
+import json
+import math
+import time
+from typing import Optional
+
+import torch
+
+from . import _lib
+from .engine import adam_hyper
+from .results import CleanResultsManager
+
+
+# ------------------------------------------------------------------ schedules (training.py:12-47)
+def linear_warmup(step, warmup_steps, base_lr=None):
+    return min(1.0, step / warmup_steps)
+
+
+def warmup_cosine_decay(step, warmup_steps, total_steps, base_lr=None):
+    if step < warmup_steps:
+        return step / warmup_steps            # factor 0 at step 0: the first update does not move weights
+    progress = (step - warmup_steps) / (total_steps - warmup_steps)
+    return 0.5 * (1 + math.cos(math.pi * progress))
+
+
+def create_scheduler(optimizer, cfg, num_batches):
+    """Same three schedules as the reference (`min_lr` is accepted and, as there, unused by
+    `warmup_decay`).  Works with torch.optim.Adam and with FusedAdam (both are Optimizers)."""
+    from torch.optim.lr_scheduler import CosineAnnealingLR, LambdaLR
+    kind = cfg.get("scheduler_type", "none")
+    if kind == "warmup_only":
+        w = cfg.get("warmup_steps", 1000)
+        return LambdaLR(optimizer, lr_lambda=lambda s: linear_warmup(s, w))
+    if kind == "decay_only":
+        return CosineAnnealingLR(optimizer, T_max=num_batches, eta_min=cfg.get("min_lr", cfg["lr"] * 0.01))
+    if kind == "warmup_decay":
+        w = cfg.get("warmup_steps", 1000)
+        return LambdaLR(optimizer, lr_lambda=lambda s: warmup_cosine_decay(s, w, num_batches))
+    return None
+
+
+# ------------------------------------------------------------------ fused optimizer (a12 + a13)
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam semantics (eps 1e-8, no weight decay / amsgrad; moments in the parameter
+    dtype) executed by libmtc.  `step()` assumes the caller already ran
+    `transcoder.make_decoder_weights_and_grad_unit_norm()` like the reference loop does;
+    `step(project=True)` fuses that projection into the W_dec update (one pass over W_dec)."""
+
+    def __init__(self, transcoder, lr=3e-4, betas=(0.9, 0.99), eps=1e-8):
+        self.transcoder = transcoder
+        super().__init__(list(transcoder.parameters()), dict(lr=lr, betas=betas, eps=eps))
+
+    @torch.no_grad()
+    def step(self, closure=None, project: bool = False):
+        if closure is not None:
+            raise _lib.MtcError("FusedAdam does not take a closure")
+        tc = self.transcoder
+        hp = tc.hot_path()
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+                h = adam_hyper(group["lr"], b1, b2, group["eps"], st["step"])
+                if p is tc.W_dec and project:
+                    g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                    hp.unitnorm_adam(p.data, g, st["exp_avg"], st["exp_avg_sq"], h, write_grad=False)
+                elif p is tc.W_enc:
+                    # feature-major storage: run on the contiguous transposed views
+                    tc._w_encT(p)
+                    g = p.grad.t()
+                    g = g if g.is_contiguous() else g.contiguous()
+                    m, v = st["exp_avg"].t(), st["exp_avg_sq"].t()
+                    if not m.is_contiguous():
+                        st["exp_avg"] = m.contiguous().t(); st["exp_avg_sq"] = v.contiguous().t()
+                        m, v = st["exp_avg"].t(), st["exp_avg_sq"].t()
+                    hp.adam_flat(p.data.t(), g, m, v, h)
+                else:
+                    g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                    hp.adam_flat(p.data, g, st["exp_avg"], st["exp_avg_sq"], h)
+        return None
+
+
+# ------------------------------------------------------------------ the loop (training.py:49-213)
+def train_transcoder(transcoder, activation_store, model, cfg):
+    """Train one transcoder.  `activation_store` is anything with `next_batch() -> (source, target)` on
+    cfg["device"] in cfg["dtype"]; `model` (the language model) is only handed through."""
+    num_batches = int(cfg["num_tokens"] // cfg["batch_size"])
+    optimizer = FusedAdam(transcoder, lr=cfg["lr"], betas=(cfg["beta1"], cfg["beta2"]))
+    scheduler = create_scheduler(optimizer, cfg, num_batches)
+    results = CleanResultsManager(cfg.get("results_root", "results"))
+    exp_dir = results.create_experiment_dir(cfg.get("model_name", "model"), cfg.get("layer", 0), num_batches,
+                                            cfg.get("experiment_description", ""))
+    log_freq = int(cfg.get("log_freq", 100))
+    log_path = exp_dir / "train_log.jsonl"
+    n_dead_at = cfg.get("n_batches_to_dead", 20)
+    out = None
+    t0 = time.time()
+
+    def metrics_of(o):
+        return {"loss": float(o["loss"].detach()), "l2_loss": float(o["l2_loss"].detach()),
+                "l0_norm": float(o["l0_norm"].detach()), "fvu": float(o["fvu"].detach()),
+                "dead_features": float(transcoder.num_batches_not_active.sum().item())}
+
+    with open(log_path, "a", encoding="utf-8") as log:
+        for i in range(num_batches):
+            source_batch, target_batch = activation_store.next_batch()
+            out = transcoder(source_batch, target_batch)
+            if i % cfg.get("perf_log_freq", 1000) == 0:
+                log_transcoder_performance(log, i, model, activation_store, transcoder)
+            if i % cfg.get("checkpoint_freq", 10000) == 0:
+                results.save_checkpoint(exp_dir, transcoder, cfg, i, metrics_of(out), is_final=False)
+            if i % log_freq == 0:
+                rec = metrics_of(out)
+                rec.update(step=i, dead_features_count=int((transcoder.num_batches_not_active >= n_dead_at).sum()),
+                           learning_rate=optimizer.param_groups[0]["lr"], elapsed_s=time.time() - t0)
+                log.write(json.dumps(rec) + "\n")
+            out["loss"].backward(retain_graph=True)
+            optimizer.step(project=True)          # unit-norm projection fused into the W_dec update
+            optimizer.zero_grad()
+            if scheduler is not None:
+                scheduler.step()
+    final_cfg = dict(cfg)
+    final_cfg["completed_steps"] = num_batches
+    if out is not None:
+        results.save_checkpoint(exp_dir, transcoder, final_cfg, num_batches, metrics_of(out), is_final=True)
+    return exp_dir
+
+
+def log_transcoder_performance(log, step, model, activation_store, transcoder):
+    """training.py:216-245: an extra batch through the transcoder under no_grad *in its current mode*
+    (in training mode this moves the threshold EMA and the dead counters, as in the reference)."""
+    source_batch, target_batch = activation_store.next_batch()
+    with torch.no_grad():
+        o = transcoder(source_batch, target_batch)
+        rec = o["transcoder_out"].float()
+        tgt = target_batch.float()
+        mse = (rec - tgt).pow(2).mean()
+        mae = (rec - tgt).abs().mean()
+        cos = torch.nn.functional.cosine_similarity(rec.flatten(), tgt.flatten(), dim=0)
+    log.write(json.dumps({"step": step, "performance/mse": float(mse), "performance/mae": float(mae),
+                          "performance/cosine_similarity": float(cos), "performance/fvu": float(o["fvu"])}) + "\n")

@@ -1,0 +1,312 @@
+"""Drop-in `MatryoshkaTranscoder` whose math runs in libmtc's HIP kernels.
+
+Mirrors the public surface of the reference class (src/models/sae.py:73-406): constructor
+arguments, parameter names / registration order / shapes, the `threshold` buffer, the
+`num_batches_not_active` attribute, the 11-key forward dict, `encode` / `decode`,
+`make_decoder_weights_and_grad_unit_norm`, and all documented side effects.  What differs is
+underneath: activations stay sparse (CSR rows / CSC features), the global TopK is a radix select,
+the nested prefix reconstructions are one running sum, and the backward is k-sparse.
+
+`W_enc` keeps the reference's shape `[A_s, D]` but its storage is feature-major (`[D, A_s]`
+contiguous, exposed as a transposed view), which is what the MFMA encoder and the per-feature
+gradient rows want; `state_dict()` round-trips with reference checkpoints unchanged.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .engine import HotPath, Selection, adam_hyper
+
+
+def _feature_major(w: torch.Tensor) -> torch.Tensor:
+    """[A_s, D] tensor whose memory is [D, A_s] row-major (w.t() is contiguous)."""
+    return w.t().contiguous().t()
+
+
+class _StepFn(torch.autograd.Function):
+    """forward: the whole HIP forward chain; backward: the k-sparse backward (a11)."""
+
+    @staticmethod
+    def forward(ctx, module, x_source, x_target, W_enc, b_enc, W_dec, b_dec):
+        need_grad = any(ctx.needs_input_grad[3:])
+        res = module._run_forward(x_source, x_target, W_enc, b_enc, W_dec, b_dec, need_grad)
+        ctx.module = module
+        ctx.res = res
+        module._last_res = res
+        ctx.mark_non_differentiable(res.x_hat, res.scalars)
+        loss32 = res.scalars[5]
+        loss = loss32.clone() if res.aux is not None else loss32.to(module.dtype)
+        return loss, res.x_hat, res.scalars
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_xhat, _g_scalars):
+        res = ctx.res
+        if res.g is None:
+            raise _lib.MtcError("backward called on a forward that did not record gradients")
+        module = ctx.module
+        dW_dec, dW_encT, db_enc, db_dec = module._run_backward(res, g_loss)
+        return None, None, None, dW_encT.t(), db_enc, dW_dec, db_dec
+
+
+class MatryoshkaTranscoder(nn.Module):
+    """Cross-layer transcoder with nested (Matryoshka) prefix groups and global batch-TopK sparsity."""
+
+    def __init__(self, cfg: dict):
+        super().__init__()
+        self.config = cfg
+        prefix_sizes = list(cfg["prefix_sizes"])
+        for a, b in zip(prefix_sizes[:-1], prefix_sizes[1:]):
+            if a > b:
+                raise ValueError(
+                    "prefix_sizes must be monotonically increasing (cumulative format). "
+                    f"Got: {prefix_sizes}")
+        self.prefix_sizes = prefix_sizes
+        self.prefix_indices = [0] + prefix_sizes
+        self.active_prefixes = len(prefix_sizes)
+        D = prefix_sizes[-1]
+        self.source_act_size = cfg.get("source_act_size", cfg.get("act_size"))
+        self.target_act_size = cfg.get("target_act_size", cfg.get("act_size"))
+
+        # same CPU RNG stream as the reference (sae.py:89,116-127): seed, W_enc draw, W_dec draw
+        torch.manual_seed(cfg["seed"])
+        w_enc = nn.init.kaiming_uniform_(torch.empty(self.source_act_size, D))
+        w_dec = nn.init.kaiming_uniform_(torch.empty(D, self.target_act_size))
+        w_dec = w_dec / w_dec.norm(dim=-1, keepdim=True)
+        self.b_enc = nn.Parameter(torch.zeros(D))
+        self.W_enc = nn.Parameter(_feature_major(w_enc))
+        self.W_dec = nn.Parameter(w_dec)
+        self.b_dec = nn.Parameter(torch.zeros(self.target_act_size))
+        self.num_batches_not_active = torch.zeros(D, device=cfg["device"])
+        self.register_buffer("threshold", torch.tensor(0.0))
+        self.x_mean = None
+        self.x_std = None
+        self._hp: Optional[HotPath] = None
+        self._last_res = None
+        self._dead_check_in = 0          # forwards until a dead feature can exist (host-side bound)
+        self.to(cfg["dtype"]).to(cfg["device"])
+
+    # ------------------------------------------------------------------ plumbing
+    @property
+    def dtype(self) -> torch.dtype:
+        return self.W_dec.dtype
+
+    def hot_path(self) -> HotPath:
+        if self._hp is None or self._hp.dtype != self.dtype:
+            self._hp = HotPath(self.source_act_size, self.target_act_size, self.prefix_sizes, self.dtype,
+                               bool(self.config.get("input_unit_norm", False)))
+        self._hp.unit_norm = bool(self.config.get("input_unit_norm", False))
+        return self._hp
+
+    def _w_encT(self, W_enc: torch.Tensor) -> torch.Tensor:
+        wt = W_enc.t()
+        if not wt.is_contiguous():       # e.g. weights assigned from a row-major tensor: re-lay once
+            with torch.no_grad():
+                self.W_enc.data = _feature_major(self.W_enc.data)
+            wt = self.W_enc.t()
+        return wt
+
+    def _check_inputs(self, x_source, x_target=None):
+        if not x_source.is_cuda:
+            raise _lib.MtcError("matryoshka_transcoder_amd computes on the GPU only (HIP kernels); got a "
+                                f"{x_source.device} input and there is no CPU fallback")
+        if x_source.dtype != self.dtype or (x_target is not None and x_target.dtype != self.dtype):
+            raise _lib.MtcError(f"inputs must have the model dtype {self.dtype}")
+
+    # ------------------------------------------------------------------ reference helper methods
+    def preprocess_input(self, x):
+        """sae.py:139-147.  Returns (x_norm, mean, std) with [.., 1] statistics, or (x, None, None)."""
+        if not self.config.get("input_unit_norm", False):
+            return x, None, None
+        self._check_inputs(x)
+        hp = self.hot_path()
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        xn, mean, std = hp.normalize(hp.desc(x2.shape[0]), x2)
+        shp = x.shape[:-1] + (1,)
+        return xn.reshape(x.shape), mean.reshape(shp), std.reshape(shp)
+
+    def postprocess_output(self, x_reconstruct, x_mean, x_std):
+        """sae.py:149-153."""
+        if self.config.get("input_unit_norm", False):
+            x_reconstruct = x_reconstruct * x_std + x_mean
+        return x_reconstruct
+
+    @torch.no_grad()
+    def make_decoder_weights_and_grad_unit_norm(self):
+        """sae.py:155-163: normalise W_dec rows and remove the radial component of W_dec.grad."""
+        if self.W_dec.grad is None:
+            raise _lib.MtcError("W_dec.grad is None: call backward() first")
+        if not self.W_dec.grad.is_contiguous():
+            self.W_dec.grad = self.W_dec.grad.contiguous()
+        self.hot_path().unitnorm_project(self.W_dec.data, self.W_dec.grad)
+
+    @torch.no_grad()
+    def update_inactive_features(self, acts):
+        """sae.py:165-169 for a dense [B, D] activation tensor (the fused forward does this from the
+        CSC column pointers instead)."""
+        col = acts.sum(0)
+        self.num_batches_not_active = torch.where(
+            col > 0, torch.zeros_like(self.num_batches_not_active),
+            self.num_batches_not_active + (col == 0).float())
+
+    @torch.no_grad()
+    def update_threshold(self, acts_topk, lr=0.01):
+        """sae.py:349-361 for a dense tensor (the fused forward uses tau from the select instead)."""
+        pos = acts_topk > 0
+        if bool(pos.any()):
+            self.threshold.copy_((1 - lr) * self.threshold + lr * acts_topk[pos].min())
+
+    # ------------------------------------------------------------------ the fused chain
+    def _select(self, hp, d, acts, training: bool) -> Selection:
+        if training:
+            sel = hp.select_topk(d, acts, int(self.config["top_k"]) * d.B)
+            hp.threshold_ema(d, sel, self.threshold)
+        else:
+            sel = hp.select_threshold(d, acts, self.threshold)
+        return sel
+
+    def _aux_may_be_active(self) -> bool:
+        """Host-side bound: a counter grows by at most 1 per forward, so after reading the device
+        maximum once we know how many forwards must pass before any feature can be dead; only then is
+        the (synchronising) check repeated.  The reference synchronises on every call (sae.py:331)."""
+        if self._dead_check_in > 0:
+            return False
+        n_dead_at = float(self.config["n_batches_to_dead"])
+        mx = float(self.num_batches_not_active.max().item())
+        if mx >= n_dead_at:
+            return True
+        self._dead_check_in = max(int(math.ceil(n_dead_at - mx)) - 1, 0)
+        return False
+
+    def _run_forward(self, x_source, x_target, W_enc, b_enc, W_dec, b_dec, need_grad: bool):
+        self._check_inputs(x_source, x_target)
+        hp = self.hot_path()
+        cfg = self.config
+        B = x_source.shape[0]
+        d = hp.desc(B)
+        x_source = x_source.contiguous()
+        x_target = x_target.contiguous()
+        if hp.unit_norm:
+            xn, mean, std = hp.normalize(d, x_source)
+            self.x_mean, self.x_std = mean.reshape(B, 1), std.reshape(B, 1)
+        else:
+            xn, mean, std = x_source, None, None
+            self.x_mean = self.x_std = None
+        acts = hp.encode(d, xn, self._w_encT(W_enc), b_enc.contiguous())
+        sel = self._select(hp, d, acts, self.training)
+        if self.num_batches_not_active.device != x_source.device:
+            self.num_batches_not_active = self.num_batches_not_active.to(x_source.device)
+        hp.build_csc(d, sel, self.num_batches_not_active)            # counters BEFORE aux (sae.py:233,242)
+        self._dead_check_in -= 1
+        aux_active = self._aux_may_be_active()
+        l1_term = float(cfg["l1_coeff"]) / (B * hp.D)
+        W_dec_c = W_dec.contiguous()
+        x_hat, g, row_stats, _, d_vals = hp.decode(
+            d, sel, W_dec_c, b_dec.contiguous(), x_target, mean, std, want_g=need_grad or aux_active,
+            want_dvals=need_grad and not aux_active, l1_term=l1_term)
+        aux = None
+        aux_rows = None
+        if aux_active:
+            aux, aux_rows = self._run_aux(hp, d, acts, sel, W_dec_c, x_target, x_hat, g, need_grad, l1_term)
+            if need_grad:
+                d_vals = hp.decode_bwd_vals(d, sel, W_dec_c, g, l1_term)
+        scalars = hp.reduce_scalars(d, row_stats, sel, hp.D, float(cfg["l1_coeff"]), float(cfg["aux_penalty"]),
+                                    aux_rows=aux_rows)
+        from .engine import ForwardResult
+        return ForwardResult(B=B, desc=d, x_norm=xn, mean=mean, std=std, acts=None, sel=sel, x_hat=x_hat,
+                             g=g if need_grad else None, d_vals=d_vals, row_stats=row_stats, scalars=scalars, aux=aux)
+
+    def _run_aux(self, hp, d, acts, sel, W_dec, x_target, x_hat, g, need_grad, l1_term):
+        raise _lib.MtcError("auxiliary dead-feature path: not built yet in this revision")
+
+    def _run_backward(self, res, g_loss):
+        hp = self.hot_path()
+        grads = hp.backward(res.desc, res.sel, res.g, res.d_vals, res.x_norm, g_loss)
+        if res.aux is not None:
+            grads = self._run_aux_backward(hp, res, g_loss, grads)
+        return grads
+
+    # ------------------------------------------------------------------ public API
+    def compute_activations(self, x_source):
+        """sae.py:171-193: returns dense (acts, acts_topk) like the reference."""
+        self._check_inputs(x_source)
+        hp = self.hot_path()
+        d = hp.desc(x_source.shape[0])
+        acts = hp.encode(d, x_source.contiguous(), self._w_encT(self.W_enc), self.b_enc)
+        sel = self._select(hp, d, acts, self.training)
+        return acts, hp.densify(d, sel, hp.D)
+
+    def forward(self, x_source, x_target):
+        """sae.py:195-269.  Returns the reference's dict; `loss` carries the autograd graph."""
+        loss, x_hat, s = _StepFn.apply(self, x_source, x_target, self.W_enc, self.b_enc, self.W_dec, self.b_dec)
+        dt = self.dtype
+        # aux inactive: a 0-dim zero in the target dtype; active: fp32 (sae.py:342-347)
+        aux_loss = s[4] if self._last_res.aux is not None else \
+            torch.zeros((), dtype=x_target.dtype, device=x_target.device)
+        return {
+            "transcoder_out": x_hat,
+            "loss": loss,
+            "l2_loss": s[0].to(dt),
+            "l1_loss": s[1].to(dt),
+            "l0_norm": s[2],
+            "l1_norm": s[3].to(dt),
+            "aux_loss": aux_loss,
+            "fvu": s[6],
+            "fvu_min": s[7],
+            "fvu_max": s[8],
+            "fvu_mean": s[9],
+        }
+
+    def encode(self, x_source):
+        """sae.py:363-387: dense sparse-feature tensor, 2-D or 3-D input; honours train/eval mode."""
+        original_shape = x_source.shape
+        x_source, x_mean, x_std = self.preprocess_input(x_source)
+        self.x_mean, self.x_std = x_mean, x_std
+        x2 = x_source.reshape(-1, x_source.shape[-1]).contiguous()
+        self._check_inputs(x2)
+        hp = self.hot_path()
+        d = hp.desc(x2.shape[0])
+        acts = hp.encode(d, x2, self._w_encT(self.W_enc), self.b_enc)
+        sel = self._select(hp, d, acts, self.training)
+        result = hp.densify(d, sel, self.prefix_indices[self.active_prefixes])
+        if len(original_shape) == 3:
+            result = result.reshape(original_shape[0], original_shape[1], -1)
+        return result
+
+    def decode(self, acts_topk):
+        """sae.py:389-406: reconstruction from a dense [N, D] feature tensor, de-normalised with the
+        statistics remembered from the last encode()."""
+        if not hasattr(self, "x_mean"):
+            raise AttributeError("decode() needs the statistics of a previous encode()")
+        self._check_inputs(acts_topk)
+        hp = self.hot_path()
+        max_idx = self.prefix_indices[self.active_prefixes]
+        if max_idx != hp.D:
+            sub = HotPath(self.source_act_size, self.target_act_size, [max_idx], self.dtype, False)
+            return self._decode_with(sub, acts_topk[:, :max_idx].contiguous(), self.W_dec[:max_idx])
+        return self._decode_with(hp, acts_topk.contiguous(), self.W_dec)
+
+    def _decode_with(self, hp, dense, W_dec):
+        import ctypes as C
+        from .engine import _p, _stream
+        N = dense.shape[0]
+        unit = bool(self.config.get("input_unit_norm", False))
+        mean = std = None
+        if unit:
+            if self.x_mean is None or self.x_mean.numel() != N:
+                raise RuntimeError(
+                    f"decode(): statistics of the last encode() cover {0 if self.x_mean is None else self.x_mean.numel()} "
+                    f"rows but {N} rows were given")
+            mean, std = self.x_mean.reshape(N).contiguous(), self.x_std.reshape(N).contiguous()
+        d = _lib.make_desc(N, hp.A_s, hp.A_t, hp.D, hp.prefix, hp.code, unit)
+        nan = torch.full((1,), float("nan"), dtype=self.dtype, device=dense.device)     # "non-zero" select mode
+        sel = hp.select_threshold(d, dense, nan)
+        x_hat = torch.empty(N, hp.A_t, dtype=self.dtype, device=dense.device)
+        _lib.check(hp.lib.mtc_decode_fwd(C.byref(d), _p(sel.row_ptr), _p(sel.col_idx), _p(sel.vals),
+                                         _p(W_dec.contiguous()), _p(self.b_dec), None, _p(mean), _p(std), _p(x_hat), None,
+                                         None, None, None, 0.0, _stream()), "mtc_decode_fwd")
+        return x_hat
