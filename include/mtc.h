@@ -192,6 +192,29 @@ int mtc_adam_flat(int32_t dtype, size_t n, void* p, const void* grad, void* exp_
 /* projection only (the reference method called on its own, sae.py:155-163) */
 int mtc_unitnorm_project(const mtc_desc* d, void* W_dec, void* grad, void* stream);
 
+/* a9  get_auxiliary_loss (sae.py:318-347), sparse.  n_dead stays on the device (int32).
+ *   mtc_aux_dead_list : dead_idx[<=D] ascending = features with cnt >= n_batches_to_dead, *n_dead_dev
+ *   mtc_aux_select    : per row, the min(top_k_aux, n_dead) largest POSITIVE acts among the dead
+ *                       columns: count, threshold bits and tie quota per row (ties: ascending feature)
+ *   mtc_aux_fill      : CSR (row_ptr from mtc_select_offsets on the counts) of those entries
+ *   mtc_aux_fwd       : x_aux = sum a W_dec[j] (no bias); e = round(x_aux) - (x_t - x_hat);
+ *                       aux_rows[b] = sum e^2; g_aux = 2 aux_penalty/(B A_t) e; g += g_aux*std_row
+ *                       (residual not detached); d_aux_vals = g_aux . W_dec[j]
+ * The aux gradients then reuse mtc_build_csc + mtc_backward_sparse(accumulate = 1). */
+int mtc_aux_dead_list(const mtc_desc* d, const float* cnt, float n_batches_to_dead, int32_t* dead_idx,
+                      int32_t* n_dead_dev, void* stream);
+int mtc_aux_select(const mtc_desc* d, const void* acts, const int32_t* dead_idx,
+                   const int32_t* n_dead_dev, int32_t top_k_aux, uint32_t* row_cnt,
+                   uint32_t* row_tau_bits, uint32_t* row_tie_quota, void* stream);
+int mtc_aux_fill(const mtc_desc* d, const void* acts, const int32_t* dead_idx,
+                 const int32_t* n_dead_dev, const uint32_t* row_tau_bits,
+                 const uint32_t* row_tie_quota, const int32_t* row_ptr, int32_t* col_idx, void* vals,
+                 void* stream);
+int mtc_aux_fwd(const mtc_desc* d, const int32_t* row_ptr, const int32_t* col_idx, const void* vals,
+                const void* W_dec, const void* x_target, const void* x_hat, const void* std,
+                float aux_penalty, float* g, float* g_aux, float* aux_rows, float* d_aux_vals,
+                void* stream);
+
 /* a15 helpers: CSR <-> dense [B][D] in the model dtype (encode returns dense, decode takes it) */
 int mtc_densify(const mtc_desc* d, const int32_t* row_ptr, const int32_t* col_idx, const void* vals,
                 int32_t max_col, void* dense, void* stream);

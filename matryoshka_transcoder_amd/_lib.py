@@ -60,6 +60,10 @@ PROTOTYPES = {
     "mtc_unitnorm_adam_rows": (C.c_int, [DP, P, P, P, P, HP, C.c_int, P]),
     "mtc_adam_flat": (C.c_int, [C.c_int32, C.c_size_t, P, P, P, P, HP, P]),
     "mtc_unitnorm_project": (C.c_int, [DP, P, P, P]),
+    "mtc_aux_dead_list": (C.c_int, [DP, P, C.c_float, P, P, P]),
+    "mtc_aux_select": (C.c_int, [DP, P, P, P, C.c_int32, P, P, P, P]),
+    "mtc_aux_fill": (C.c_int, [DP, P, P, P, P, P, P, P, P, P]),
+    "mtc_aux_fwd": (C.c_int, [DP, P, P, P, P, P, P, P, C.c_float, P, P, P, P, P]),
     "mtc_densify": (C.c_int, [DP, P, P, P, C.c_int32, P, P]),
 }
 

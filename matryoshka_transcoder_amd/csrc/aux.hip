@@ -1,0 +1,262 @@
+// K3b: auxiliary dead-feature loss (sae.py:318-347) in sparse form.
+//
+//   dead     = num_batches_not_active >= n_batches_to_dead           -> compact ascending index list
+//   per row  : top-min(k_aux, n_dead) of acts[b, dead]               -> per-row radix select in LDS
+//   x_aux_b  = sum_j a_bj W_dec[j]          (no b_dec)               -> same row gather as the decode
+//   e_b      = round(x_aux_b) - (x_t - x_hat)_b   (fp32; the residual is NOT detached)
+//   aux      = aux_penalty * mean(e^2)
+//   g_aux    = 2 aux_penalty / (B A_t) * e ;  g += g_aux * std_row ;  d a_bj = g_aux_b . W_dec[j]
+// Zeros are never selected (a zero activation contributes nothing forward or backward); ties at a
+// row's threshold are taken in ascending feature order.  n_dead stays on the device.
+#include "common.hpp"
+#include "rowops.hpp"
+
+namespace mtc {
+
+// ---------------------------------------------------------------- dead list (one workgroup)
+__global__ __launch_bounds__(1024) void dead_list_kernel(int D, const float* __restrict__ cnt, float n_to_dead,
+                                                         int32_t* __restrict__ dead_idx, int32_t* __restrict__ n_dead) {
+    __shared__ uint32_t sm[16];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int per = (D + 1023) / 1024;
+    const int j0 = t * per, j1 = min(D, j0 + per);
+    uint32_t mine = 0;
+    for (int j = j0; j < j1; ++j) mine += cnt[j] >= n_to_dead ? 1u : 0u;
+    uint32_t inc = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t n = __shfl_up(inc, o, 64); if (lane >= o) inc += n; }
+    if (lane == 63) sm[w] = inc;
+    __syncthreads();
+    uint32_t base = inc - mine, total = 0;
+    for (int i = 0; i < 16; ++i) { if (i < w) base += sm[i]; total += sm[i]; }
+    for (int j = j0; j < j1; ++j)
+        if (cnt[j] >= n_to_dead) dead_idx[base++] = j;
+    if (t == 0) *n_dead = (int32_t)total;
+}
+
+// ---------------------------------------------------------------- per-row top-k over the dead columns
+// one workgroup (256 threads) per row; 4096-bin LDS histogram per radix level
+template <int DT>
+__global__ __launch_bounds__(256) void aux_select_kernel(const void* __restrict__ acts, int D, const int32_t* __restrict__ dead_idx,
+                                                         const int32_t* __restrict__ n_dead_p, int k_aux_max,
+                                                         uint32_t* __restrict__ row_cnt, uint32_t* __restrict__ row_tau,
+                                                         uint32_t* __restrict__ row_quota) {
+    __shared__ uint32_t hist[4096];
+    __shared__ uint32_t tsum[256];
+    __shared__ uint32_t s_bin, s_above, s_total;
+    const int t = threadIdx.x;
+    const int row = blockIdx.x;
+    const int n_dead = *n_dead_p;
+    const uint32_t k_aux = (uint32_t)min(k_aux_max, n_dead);
+    if (n_dead == 0 || k_aux == 0) {
+        if (t == 0) { row_cnt[row] = 0; row_tau[row] = 0; row_quota[row] = 0; }
+        return;
+    }
+    const size_t base = (size_t)row * D;
+    const int levels = DT == MTC_BF16 ? 2 : 3;
+    uint32_t prefix = 0, k_rem = k_aux, n_gt = 0;
+    bool all_pos = false;
+    for (int level = 0; level < levels && !all_pos; ++level) {
+        const int sh = level == 0 ? 19 : (level == 1 ? 7 : 0);
+        const uint32_t fm = level == 2 ? 0x7fu : 0xfffu;
+        const uint32_t pm = level == 0 ? 0u : (level == 1 ? 0xfff80000u : 0xffffff80u);
+        for (int i = t; i < 4096; i += 256) hist[i] = 0;
+        __syncthreads();
+        for (int i = t; i < n_dead; i += 256) {
+            const uint32_t k = key_of<DT>(acts, base + dead_idx[i]);
+            if (k != 0 && k <= 0x7f800000u && ((k ^ prefix) & pm) == 0) atomicAdd(&hist[(k >> sh) & fm], 1u);
+        }
+        __syncthreads();
+        // thread t owns bins [16t, 16t+15]; suffix scan over threads
+        uint32_t mine = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mine += hist[16 * t + i];
+        tsum[t] = mine;
+        if (t == 0) { s_bin = 0xffffffffu; s_above = 0; }
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            const uint32_t add = t + off < 256 ? tsum[t + off] : 0u;
+            __syncthreads();
+            tsum[t] += add;
+            __syncthreads();
+        }
+        uint32_t above = t + 1 < 256 ? tsum[t + 1] : 0u;
+        for (int i = 15; i >= 0; --i) {
+            const uint32_t h = hist[16 * t + i];
+            if (above < k_rem && k_rem <= above + h) { s_bin = 16 * t + i; s_above = above; }
+            above += h;
+        }
+        if (t == 0) s_total = tsum[0];
+        __syncthreads();
+        if (s_bin == 0xffffffffu) {            // fewer positives than k_aux: take them all
+            all_pos = true; n_gt = s_total;
+        } else {
+            n_gt += s_above; k_rem -= s_above; prefix |= s_bin << sh;
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        row_cnt[row] = all_pos ? n_gt : k_aux;
+        row_tau[row] = all_pos ? 0u : prefix;
+        row_quota[row] = all_pos ? 0u : k_rem;
+    }
+}
+
+// wave per row: ordered compaction of the row's aux entries
+template <int DT>
+__global__ __launch_bounds__(256) void aux_fill_kernel(const void* __restrict__ acts, int B, int D,
+                                                       const int32_t* __restrict__ dead_idx, const int32_t* __restrict__ n_dead_p,
+                                                       const uint32_t* __restrict__ row_tau, const uint32_t* __restrict__ row_quota,
+                                                       const int32_t* __restrict__ row_ptr, int32_t* __restrict__ col_idx,
+                                                       void* __restrict__ vals) {
+    typedef typename DType<DT>::T T;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B) return;
+    const int n_dead = *n_dead_p;
+    const uint32_t tau = row_tau[row], quota = row_quota[row];
+    const size_t base = (size_t)row * D;
+    uint32_t out = (uint32_t)row_ptr[row], ties_seen = 0;
+    T* vout = reinterpret_cast<T*>(vals);
+    for (int i0 = 0; i0 < n_dead; i0 += 64) {
+        const int i = i0 + lane;
+        int col = 0; uint32_t k = 0;
+        if (i < n_dead) { col = dead_idx[i]; k = key_of<DT>(acts, base + col); }
+        const bool ok = k != 0 && k <= 0x7f800000u;
+        const bool gt = ok && k > tau;
+        const bool eq = ok && quota && k == tau;
+        bool sel = gt;
+        const uint64_t eqb = __ballot(eq);
+        if (eqb) {
+            const uint32_t rank = ties_seen + (uint32_t)__popcll(eqb & ((1ull << lane) - 1ull));
+            if (eq && rank < quota) sel = true;
+            ties_seen += (uint32_t)__popcll(eqb);
+        }
+        const uint64_t sb = __ballot(sel);
+        if (sel) {
+            const uint32_t pos = out + (uint32_t)__popcll(sb & ((1ull << lane) - 1ull));
+            col_idx[pos] = col;
+            vout[pos] = reinterpret_cast<const T*>(acts)[base + col];
+        }
+        out += (uint32_t)__popcll(sb);
+    }
+}
+
+// wave per row: aux reconstruction, residual error, loss partial, gradient updates, d(aux acts)
+template <int DT, int NC>
+__global__ __launch_bounds__(256) void aux_fwd_kernel(int B, int A_t, int unit_norm, float coef_aux /* 2*aux_penalty/(B*A_t) */,
+                                                      const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col_idx,
+                                                      const void* __restrict__ vals, const void* __restrict__ W_dec,
+                                                      const void* __restrict__ x_target, const void* __restrict__ x_hat,
+                                                      const void* __restrict__ std_p, float* __restrict__ g,
+                                                      float* __restrict__ g_aux, float* __restrict__ aux_rows,
+                                                      float* __restrict__ d_aux_vals) {
+    typedef DType<DT> D_;
+    typedef typename D_::T T;
+    RowCtx<DT, NC> rc;
+    rc.lane = threadIdx.x & 63;
+    rc.nch = A_t >> 3;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B) return;
+    const int e_begin = row_ptr[row], e_end = row_ptr[row + 1];
+    float acc[NC][8];
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[c][k] = 0.f;
+    const T* vp = reinterpret_cast<const T*>(vals);
+    for (int e0 = e_begin; e0 < e_end; e0 += 64) {
+        const int nb = min(64, e_end - e0);
+        const int my_col = rc.lane < nb ? col_idx[e0 + rc.lane] : 0;
+        const float my_val = rc.lane < nb ? D_::ld(vp + e0 + rc.lane) : 0.f;
+        accumulate_run<DT, NC>(rc, W_dec, A_t, my_col, my_val, 0, nb, acc);
+    }
+    const float stdv = unit_norm ? D_::ld(reinterpret_cast<const T*>(std_p) + row) : 1.f;
+    float sse = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        if (rc.valid(c)) {
+            const size_t off = (size_t)row * A_t + rc.off(c);
+            float t[8], h[8], gg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ga[8];
+            load8<DT>(x_target, off, t);
+            load8<DT>(x_hat, off, h);
+            if (g) load8<MTC_F32>(g, off, gg);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float e = D_::rnd(acc[c][k]) - (t[k] - h[k]);
+                sse = fmaf(e, e, sse);
+                ga[k] = coef_aux * e;
+                acc[c][k] = ga[k];                       // acc now holds g_aux for the second sweep
+                gg[k] += ga[k] * stdv;
+            }
+            if (g) store8<MTC_F32>(g, off, gg);
+            if (g_aux) store8<MTC_F32>(g_aux, off, ga);
+        }
+    }
+    sse = wave_sum(sse);
+    if (rc.lane == 0) aux_rows[row] = sse;
+    if (d_aux_vals) {
+        for (int e0 = e_begin; e0 < e_end; e0 += 64) {
+            const int nb = min(64, e_end - e0);
+            const int my_col = rc.lane < nb ? col_idx[e0 + rc.lane] : 0;
+            dot_run<DT, NC>(rc, W_dec, A_t, my_col, nb, acc, 0.f, d_aux_vals + e0);
+        }
+    }
+}
+
+}  // namespace mtc
+
+using namespace mtc;
+
+extern "C" int mtc_aux_dead_list(const mtc_desc* d, const float* cnt, float n_batches_to_dead, int32_t* dead_idx,
+                                 int32_t* n_dead_dev, void* stream) {
+    if (check_desc(d, "mtc_aux_dead_list")) return -1;
+    MTC_REQUIRE(cnt && dead_idx && n_dead_dev, "mtc_aux_dead_list: null pointer");
+    hipLaunchKernelGGL(dead_list_kernel, dim3(1), dim3(1024), 0, as_stream(stream), d->D, cnt, n_batches_to_dead, dead_idx,
+                       n_dead_dev);
+    return check_launch("mtc_aux_dead_list");
+}
+
+extern "C" int mtc_aux_select(const mtc_desc* d, const void* acts, const int32_t* dead_idx, const int32_t* n_dead_dev,
+                              int32_t top_k_aux, uint32_t* row_cnt, uint32_t* row_tau_bits, uint32_t* row_tie_quota,
+                              void* stream) {
+    if (check_desc(d, "mtc_aux_select")) return -1;
+    MTC_REQUIRE(acts && dead_idx && n_dead_dev && row_cnt && row_tau_bits && row_tie_quota, "mtc_aux_select: null pointer");
+    MTC_REQUIRE(top_k_aux >= 0, "mtc_aux_select: top_k_aux must be >= 0");
+    if (d->dtype == MTC_BF16)
+        hipLaunchKernelGGL(aux_select_kernel<MTC_BF16>, dim3(d->B), dim3(256), 0, as_stream(stream), acts, d->D, dead_idx,
+                           n_dead_dev, top_k_aux, row_cnt, row_tau_bits, row_tie_quota);
+    else
+        hipLaunchKernelGGL(aux_select_kernel<MTC_F32>, dim3(d->B), dim3(256), 0, as_stream(stream), acts, d->D, dead_idx,
+                           n_dead_dev, top_k_aux, row_cnt, row_tau_bits, row_tie_quota);
+    return check_launch("mtc_aux_select");
+}
+
+extern "C" int mtc_aux_fill(const mtc_desc* d, const void* acts, const int32_t* dead_idx, const int32_t* n_dead_dev,
+                            const uint32_t* row_tau_bits, const uint32_t* row_tie_quota, const int32_t* row_ptr,
+                            int32_t* col_idx, void* vals, void* stream) {
+    if (check_desc(d, "mtc_aux_fill")) return -1;
+    MTC_REQUIRE(acts && dead_idx && n_dead_dev && row_tau_bits && row_tie_quota && row_ptr && col_idx && vals,
+                "mtc_aux_fill: null pointer");
+    const dim3 grid((d->B + 3) / 4), block(256);
+    if (d->dtype == MTC_BF16)
+        hipLaunchKernelGGL(aux_fill_kernel<MTC_BF16>, grid, block, 0, as_stream(stream), acts, d->B, d->D, dead_idx, n_dead_dev,
+                           row_tau_bits, row_tie_quota, row_ptr, col_idx, vals);
+    else
+        hipLaunchKernelGGL(aux_fill_kernel<MTC_F32>, grid, block, 0, as_stream(stream), acts, d->B, d->D, dead_idx, n_dead_dev,
+                           row_tau_bits, row_tie_quota, row_ptr, col_idx, vals);
+    return check_launch("mtc_aux_fill");
+}
+
+extern "C" int mtc_aux_fwd(const mtc_desc* d, const int32_t* row_ptr, const int32_t* col_idx, const void* vals,
+                           const void* W_dec, const void* x_target, const void* x_hat, const void* std, float aux_penalty,
+                           float* g, float* g_aux, float* aux_rows, float* d_aux_vals, void* stream) {
+    if (check_desc(d, "mtc_aux_fwd")) return -1;
+    MTC_REQUIRE(row_ptr && col_idx && vals && W_dec && x_target && x_hat && aux_rows, "mtc_aux_fwd: null pointer");
+    MTC_REQUIRE(!d->unit_norm || std, "mtc_aux_fwd: unit_norm needs std");
+    MTC_REQUIRE(!d_aux_vals || g_aux, "mtc_aux_fwd: d_aux_vals needs g_aux");
+    const float coef_aux = (float)(2.0 * (double)aux_penalty / ((double)d->B * (double)d->A_t));
+    DISPATCH_NC(d->dtype, nc_for(d->A_t), aux_fwd_kernel, dim3((d->B + 3) / 4), dim3(256), as_stream(stream), d->B, d->A_t,
+                d->unit_norm, coef_aux, row_ptr, col_idx, vals, W_dec, x_target, x_hat, std, g, g_aux, aux_rows, d_aux_vals);
+    return check_launch("mtc_aux_fwd");
+}

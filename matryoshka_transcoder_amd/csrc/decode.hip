@@ -10,6 +10,7 @@
 // When `d_vals` is requested the same wave sweeps its entries a second time with g in registers
 // (the decoder rows it needs were just touched, so the second sweep is served by L2 / MALL).
 #include "common.hpp"
+#include "rowops.hpp"
 
 namespace mtc {
 
@@ -20,58 +21,6 @@ struct DecodeParams {
     float coef;            // 2 / (B * A_t)
     float l1_term;         // l1_coeff / (B * D_total)
 };
-
-template <int DT, int NC>
-struct RowCtx {
-    // chunk i of this lane covers elements [(lane + 64 i) * 8, +8)
-    int lane, nch;
-    __device__ __forceinline__ bool valid(int i) const { return lane + 64 * i < nch; }
-    __device__ __forceinline__ size_t off(int i) const { return (size_t)(lane + 64 * i) * 8; }
-};
-
-// acc += a * W_dec[j] for `n` entries starting at index i0 of the lane-resident batch (cols/vals)
-template <int DT, int NC>
-__device__ __forceinline__ void accumulate_run(const RowCtx<DT, NC>& rc, const void* __restrict__ W_dec, int A_t,
-                                               int my_col, float my_val, int i0, int n, float (&acc)[NC][8]) {
-    for (int i = i0; i < i0 + n; ++i) {
-        const int j = __builtin_amdgcn_readlane(my_col, i);
-        const float a = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_val), i));
-        const size_t rowoff = (size_t)j * A_t;
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            if (rc.valid(c)) {
-                float w[8];
-                load8<DT>(W_dec, rowoff + rc.off(c), w);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) acc[c][k] = fmaf(a, w[k], acc[c][k]);
-            }
-        }
-    }
-}
-
-// d_vals[e] = g . W_dec[j] + l1_term for `n` entries
-template <int DT, int NC>
-__device__ __forceinline__ void dot_run(const RowCtx<DT, NC>& rc, const void* __restrict__ W_dec, int A_t, int my_col,
-                                        int n, const float (&g)[NC][8], float l1_term, float* __restrict__ d_vals_out) {
-    float mine = 0.f;
-    for (int i = 0; i < n; ++i) {
-        const int j = __builtin_amdgcn_readlane(my_col, i);
-        const size_t rowoff = (size_t)j * A_t;
-        float p = 0.f;
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            if (rc.valid(c)) {
-                float w[8];
-                load8<DT>(W_dec, rowoff + rc.off(c), w);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) p = fmaf(g[c][k], w[k], p);
-            }
-        }
-        p = wave_sum(p);
-        if (rc.lane == i) mine = p + l1_term;
-    }
-    if (rc.lane < n) d_vals_out[rc.lane] = mine;
-}
 
 // Epilogue at a prefix boundary: reconstruction in the model dtype, squared error against target.
 // LAST: also x_hat, g (kept in acc on return when KEEP_G), target moments.
@@ -382,8 +331,6 @@ __global__ __launch_bounds__(1024) void reduce_scalars_kernel(int B, int A_t, in
     scalars[12] = scalars[13] = scalars[14] = scalars[15] = 0.f;
 }
 
-static int nc_for(int A) { return ((A >> 3) + 63) / 64; }
-
 static DecodeParams make_params(const mtc_desc* d, float l1_term) {
     DecodeParams p;
     p.B = d->B; p.A_t = d->A_t; p.G = d->G;
@@ -398,29 +345,6 @@ static DecodeParams make_params(const mtc_desc* d, float l1_term) {
 }  // namespace mtc
 
 using namespace mtc;
-
-// NC = 16-byte-chunks-of-8-elements per lane; instantiate the sizes the supported widths need
-#define DISPATCH_NC(dt, nc, KERNEL, grid, block, stream, ...)                                                  \
-    do {                                                                                                        \
-        const int nc_ = (nc);                                                                                   \
-        if ((dt) == MTC_BF16) {                                                                                 \
-            if (nc_ <= 1) hipLaunchKernelGGL((KERNEL<MTC_BF16, 1>), grid, block, 0, stream, __VA_ARGS__);       \
-            else if (nc_ <= 2) hipLaunchKernelGGL((KERNEL<MTC_BF16, 2>), grid, block, 0, stream, __VA_ARGS__);  \
-            else if (nc_ <= 3) hipLaunchKernelGGL((KERNEL<MTC_BF16, 3>), grid, block, 0, stream, __VA_ARGS__);  \
-            else if (nc_ <= 5) hipLaunchKernelGGL((KERNEL<MTC_BF16, 5>), grid, block, 0, stream, __VA_ARGS__);  \
-            else if (nc_ <= 7) hipLaunchKernelGGL((KERNEL<MTC_BF16, 7>), grid, block, 0, stream, __VA_ARGS__);  \
-            else if (nc_ <= 9) hipLaunchKernelGGL((KERNEL<MTC_BF16, 9>), grid, block, 0, stream, __VA_ARGS__);  \
-            else hipLaunchKernelGGL((KERNEL<MTC_BF16, 16>), grid, block, 0, stream, __VA_ARGS__);               \
-        } else {                                                                                                \
-            if (nc_ <= 1) hipLaunchKernelGGL((KERNEL<MTC_F32, 1>), grid, block, 0, stream, __VA_ARGS__);        \
-            else if (nc_ <= 2) hipLaunchKernelGGL((KERNEL<MTC_F32, 2>), grid, block, 0, stream, __VA_ARGS__);   \
-            else if (nc_ <= 3) hipLaunchKernelGGL((KERNEL<MTC_F32, 3>), grid, block, 0, stream, __VA_ARGS__);   \
-            else if (nc_ <= 5) hipLaunchKernelGGL((KERNEL<MTC_F32, 5>), grid, block, 0, stream, __VA_ARGS__);   \
-            else if (nc_ <= 7) hipLaunchKernelGGL((KERNEL<MTC_F32, 7>), grid, block, 0, stream, __VA_ARGS__);   \
-            else if (nc_ <= 9) hipLaunchKernelGGL((KERNEL<MTC_F32, 9>), grid, block, 0, stream, __VA_ARGS__);   \
-            else hipLaunchKernelGGL((KERNEL<MTC_F32, 16>), grid, block, 0, stream, __VA_ARGS__);                \
-        }                                                                                                       \
-    } while (0)
 
 extern "C" int mtc_decode_fwd(const mtc_desc* d, const int32_t* row_ptr, const int32_t* col_idx, const void* vals,
                               const void* W_dec, const void* b_dec, const void* x_target, const void* mean,

@@ -193,8 +193,10 @@ class HotPath:
         return scalars
 
     # ------------------------------------------------------------------ a11
-    def backward(self, d, sel: Selection, g, d_vals, x_norm, scale: Optional[torch.Tensor], grads=None):
-        """Dense gradients (model dtype) for W_dec [D,A_t], W_encT [D,A_s], b_enc [D], b_dec [A_t]."""
+    def backward(self, d, sel: Selection, g, d_vals, x_norm, scale: Optional[torch.Tensor], grads=None,
+                 with_colsum: bool = True):
+        """Dense gradients (model dtype) for W_dec [D,A_t], W_encT [D,A_s], b_enc [D], b_dec [A_t].
+        `grads` given = accumulate into them (aux contributions)."""
         dev = g.device
         if grads is None:
             dW_dec = torch.empty(self.D, self.A_t, dtype=self.dtype, device=dev)
@@ -210,10 +212,48 @@ class HotPath:
         check(self.lib.mtc_backward_sparse(C.byref(d), _p(sel.col_ptr), _p(sel.csc_row), _p(sel.csc_pos), _p(sel.vals),
                                            _p(d_vals), _p(g), _p(x_norm), _p(scale), _p(dW_dec), _p(dW_encT), _p(db_enc),
                                            acc, _stream()), "mtc_backward_sparse")
+        if not with_colsum:
+            return dW_dec, dW_encT, db_enc, db_dec
         ws_bytes = self.lib.mtc_colsum_workspace_bytes(C.byref(d))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         check(self.lib.mtc_colsum(C.byref(d), _p(g), _p(scale), _p(ws), ws_bytes, _p(db_dec), acc, _stream()), "mtc_colsum")
         return dW_dec, dW_encT, db_enc, db_dec
+
+    # ------------------------------------------------------------------ a9
+    def aux_forward(self, d, acts, dead_cnt, n_batches_to_dead: float, top_k_aux: int, aux_penalty: float, W_dec,
+                    x_target, x_hat, std, g, need_grad: bool):
+        """Sparse aux path; returns (aux Selection, g_aux, aux_rows[B], d_aux_vals).  g is updated in place."""
+        dev = acts.device
+        lib, s = self.lib, _stream()
+        B = d.B
+        dead_idx = torch.empty(self.D, dtype=torch.int32, device=dev)
+        n_dead = torch.empty(1, dtype=torch.int32, device=dev)
+        check(lib.mtc_aux_dead_list(C.byref(d), _p(dead_cnt), float(n_batches_to_dead), _p(dead_idx), _p(n_dead), s),
+              "mtc_aux_dead_list")
+        row_cnt = torch.empty(B, dtype=torch.int32, device=dev)
+        row_tau = torch.empty(B, dtype=torch.int32, device=dev)
+        row_quota = torch.empty(B, dtype=torch.int32, device=dev)
+        check(lib.mtc_aux_select(C.byref(d), _p(acts), _p(dead_idx), _p(n_dead), int(top_k_aux), _p(row_cnt), _p(row_tau),
+                                 _p(row_quota), s), "mtc_aux_select")
+        st = torch.empty(16, dtype=torch.int32, device=dev)
+        zeros = torch.zeros(B, dtype=torch.int32, device=dev)
+        row_ptr = torch.empty(B + 1, dtype=torch.int32, device=dev)
+        tie_take = torch.empty(B, dtype=torch.int32, device=dev)
+        check(lib.mtc_select_init(_p(st), 0, s), "mtc_select_init")
+        check(lib.mtc_select_offsets(C.byref(d), _p(row_cnt), _p(zeros), None, _p(st), _p(row_ptr), _p(tie_take), s),
+              "mtc_select_offsets")
+        cap = max(B * min(int(top_k_aux), self.D), 1)
+        col_idx = torch.empty(cap, dtype=torch.int32, device=dev)
+        vals = torch.empty(cap, dtype=self.dtype, device=dev)
+        check(lib.mtc_aux_fill(C.byref(d), _p(acts), _p(dead_idx), _p(n_dead), _p(row_tau), _p(row_quota), _p(row_ptr),
+                               _p(col_idx), _p(vals), s), "mtc_aux_fill")
+        sel = Selection(st, row_ptr, col_idx, vals)
+        g_aux = torch.empty(B, self.A_t, dtype=torch.float32, device=dev)
+        aux_rows = torch.empty(B, dtype=torch.float32, device=dev)
+        d_aux = torch.empty(cap, dtype=torch.float32, device=dev) if need_grad else None
+        check(lib.mtc_aux_fwd(C.byref(d), _p(row_ptr), _p(col_idx), _p(vals), _p(W_dec), _p(x_target), _p(x_hat), _p(std),
+                              float(aux_penalty), _p(g), _p(g_aux), _p(aux_rows), _p(d_aux), s), "mtc_aux_fwd")
+        return sel, g_aux, aux_rows, d_aux
 
     # ------------------------------------------------------------------ a12 / a13
     def unitnorm_project(self, W_dec, grad):

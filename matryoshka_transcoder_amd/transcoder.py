@@ -81,7 +81,7 @@ class MatryoshkaTranscoder(nn.Module):
         self.W_enc = nn.Parameter(_feature_major(w_enc))
         self.W_dec = nn.Parameter(w_dec)
         self.b_dec = nn.Parameter(torch.zeros(self.target_act_size))
-        self.num_batches_not_active = torch.zeros(D, device=cfg["device"])
+        self._cnt = torch.zeros(D, device=cfg["device"])          # num_batches_not_active (fp32, not a buffer)
         self.register_buffer("threshold", torch.tensor(0.0))
         self.x_mean = None
         self.x_std = None
@@ -91,6 +91,18 @@ class MatryoshkaTranscoder(nn.Module):
         self.to(cfg["dtype"]).to(cfg["device"])
 
     # ------------------------------------------------------------------ plumbing
+    @property
+    def num_batches_not_active(self) -> torch.Tensor:
+        """Dead-feature counters (sae.py:134).  Handing the tensor out (or replacing it) voids the
+        host-side "no feature can be dead yet" bound, because the caller may edit it in place."""
+        self._dead_check_in = 0
+        return self._cnt
+
+    @num_batches_not_active.setter
+    def num_batches_not_active(self, value: torch.Tensor) -> None:
+        self._dead_check_in = 0
+        self._cnt = value
+
     @property
     def dtype(self) -> torch.dtype:
         return self.W_dec.dtype
@@ -149,9 +161,7 @@ class MatryoshkaTranscoder(nn.Module):
         """sae.py:165-169 for a dense [B, D] activation tensor (the fused forward does this from the
         CSC column pointers instead)."""
         col = acts.sum(0)
-        self.num_batches_not_active = torch.where(
-            col > 0, torch.zeros_like(self.num_batches_not_active),
-            self.num_batches_not_active + (col == 0).float())
+        self.num_batches_not_active = torch.where(col > 0, torch.zeros_like(self._cnt), self._cnt + (col == 0).float())
 
     @torch.no_grad()
     def update_threshold(self, acts_topk, lr=0.01):
@@ -176,7 +186,7 @@ class MatryoshkaTranscoder(nn.Module):
         if self._dead_check_in > 0:
             return False
         n_dead_at = float(self.config["n_batches_to_dead"])
-        mx = float(self.num_batches_not_active.max().item())
+        mx = float(self._cnt.max().item())
         if mx >= n_dead_at:
             return True
         self._dead_check_in = max(int(math.ceil(n_dead_at - mx)) - 1, 0)
@@ -198,9 +208,9 @@ class MatryoshkaTranscoder(nn.Module):
             self.x_mean = self.x_std = None
         acts = hp.encode(d, xn, self._w_encT(W_enc), b_enc.contiguous())
         sel = self._select(hp, d, acts, self.training)
-        if self.num_batches_not_active.device != x_source.device:
-            self.num_batches_not_active = self.num_batches_not_active.to(x_source.device)
-        hp.build_csc(d, sel, self.num_batches_not_active)            # counters BEFORE aux (sae.py:233,242)
+        if self._cnt.device != x_source.device or self._cnt.dtype != torch.float32:
+            self._cnt = self._cnt.to(device=x_source.device, dtype=torch.float32)
+        hp.build_csc(d, sel, self._cnt)                              # counters BEFORE aux (sae.py:233,242)
         self._dead_check_in -= 1
         aux_active = self._aux_may_be_active()
         l1_term = float(cfg["l1_coeff"]) / (B * hp.D)
@@ -221,7 +231,19 @@ class MatryoshkaTranscoder(nn.Module):
                              g=g if need_grad else None, d_vals=d_vals, row_stats=row_stats, scalars=scalars, aux=aux)
 
     def _run_aux(self, hp, d, acts, sel, W_dec, x_target, x_hat, g, need_grad, l1_term):
-        raise _lib.MtcError("auxiliary dead-feature path: not built yet in this revision")
+        cfg = self.config
+        std = self.x_std.reshape(-1).contiguous() if hp.unit_norm else None
+        asel, g_aux, aux_rows, d_aux = hp.aux_forward(
+            d, acts, self._cnt, float(cfg["n_batches_to_dead"]), int(cfg["top_k_aux"]),
+            float(cfg["aux_penalty"]), W_dec, x_target, x_hat, std, g, need_grad)
+        if need_grad:
+            hp.build_csc(d, asel, None)
+        return dict(sel=asel, g_aux=g_aux, d_vals=d_aux), aux_rows
+
+    def _run_aux_backward(self, hp, res, g_loss, grads):
+        a = res.aux
+        return hp.backward(res.desc, a["sel"], a["g_aux"], a["d_vals"], res.x_norm, g_loss, grads=grads,
+                           with_colsum=False)
 
     def _run_backward(self, res, g_loss):
         hp = self.hot_path()

@@ -248,7 +248,9 @@ def forward(params, state, x_source, x_target, cfg, training: bool = True, acts_
         dead_idx = torch.nonzero(dead).flatten()
         k_aux = min(cfg["top_k_aux"], n_dead)
         sub = acts[:, dead_idx]                                                   # [B, n_dead] dt
-        tv, ti = torch.topk(sub.to(F32), k_aux, dim=-1)
+        # per-row top-k_aux; ties in ascending feature order (torch.topk leaves ties unspecified)
+        tv, ti = torch.sort(sub.to(F32), dim=-1, descending=True, stable=True)
+        tv, ti = tv[:, :k_aux], ti[:, :k_aux]
         keep = tv > 0                                                             # zeros add nothing
         a_rows = torch.arange(B)[:, None].expand(B, k_aux)[keep]
         a_cols = dead_idx[ti][keep]

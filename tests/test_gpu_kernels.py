@@ -233,3 +233,45 @@ def test_unitnorm_adam_against_oracle(dt, gpu_lib):
     hp.adam_flat(pd, gdv, mdv, vdv, adam_hyper(3e-4, 0.9, 0.99, 1e-8, 1))
     torch.cuda.synchronize()
     _close(pd, pr, rt, at, "flat p"); _close(mdv, mr, rt * 2, at, "flat m"); _close(vdv, vr, rt * 2, at * 1e-2, "flat v")
+
+
+@pytest.mark.parametrize("name", ["fp32_aux", "fp32_aux_unit", "bf16_aux"])
+def test_aux_path_against_oracle(name, gpu_lib):
+    """a9: dead list, per-row top-k_aux, aux reconstruction / loss, and every gradient with aux active."""
+    from matryoshka_transcoder_amd.transcoder import MatryoshkaTranscoder
+    fx, cfg = load_golden(name)
+    dt = cfg["dtype"]
+    f32 = dt == torch.float32
+    m = MatryoshkaTranscoder(dict(cfg, device=DEV))
+    m.load_state_dict({k: v.to(DEV) for k, v in fx["init"].items()})
+    m.num_batches_not_active = fx["cnt0"].clone().to(DEV)
+    s0 = fx["steps"][0]
+    xs, xt = s0["x_source"], s0["x_target"]
+    out = m(xs.to(DEV), xt.to(DEV))
+    res = m._last_res
+    assert res.aux is not None
+    params = {k: v.clone() for k, v in fx["init"].items()}
+    acts_gpu = m.hot_path().encode(res.desc, res.x_norm, m.W_enc.t(), m.b_enc).cpu()
+    o, new, inter = R.forward(params, {"num_batches_not_active": fx["cnt0"].clone()}, xs, xt, cfg, acts_override=acts_gpu)
+    aux = inter["aux"]
+    asel = res.aux["sel"]
+    rp = asel.row_ptr.cpu().long()
+    n = int(rp[-1])
+    assert n == aux["rows"].numel()
+    B, D = xs.shape[0], cfg["prefix_sizes"][-1]
+    rows = torch.repeat_interleave(torch.arange(B), rp[1:] - rp[:-1])
+    got = set((rows * D + asel.col_idx.cpu()[:n].long()).tolist())
+    want = set((aux["rows"] * D + aux["cols"]).tolist())
+    assert got == want, "aux selection differs from the oracle's"
+    rt, at = (1e-4, 1e-7) if f32 else (2e-2, 2e-5)
+    _close(out["aux_loss"], o["aux_loss"], rt, at, "aux_loss")
+    _close(out["loss"], o["loss"], rt, at, "loss")
+    assert out["loss"].dtype == torch.float32 and out["aux_loss"].dtype == torch.float32
+    out["loss"].backward()
+    grads = R.backward(params, xs, xt, cfg, inter)
+    for k in ("W_enc", "W_dec", "b_enc", "b_dec"):
+        _close(getattr(m, k).grad, grads[k], rt, at * (10 if k == "b_dec" else 1), f"grad {k}")
+    # and against the reference's own autograd (fixture)
+    if f32:
+        for k in ("W_enc", "W_dec", "b_enc", "b_dec"):
+            _close(getattr(m, k).grad, s0["grads"][k], 1e-4, 1e-7, f"grad {k} vs reference")

@@ -44,7 +44,7 @@ def test_init_and_state_dict_layout(name, gpu_lib):
     assert m.W_enc.t().is_contiguous()                    # feature-major storage behind the reference shape
 
 
-@pytest.mark.parametrize("name", NOAUX)
+@pytest.mark.parametrize("name", SMALL_CASES)
 @pytest.mark.parametrize("optim", ["fused", "fused_project", "stock"])
 def test_three_steps_vs_reference_fixture(name, optim, gpu_lib):
     from matryoshka_transcoder_amd.training import FusedAdam, create_scheduler
@@ -185,7 +185,6 @@ def test_full_size_properties_gemma2_2b(gpu_lib):
         out["loss"].backward()
         gW = m.W_dec.grad
         fired = torch.zeros(D, dtype=torch.bool); fired[cols] = True
-        assert torch.equal((gW.abs().sum(-1) > 0).cpu() | ~fired, torch.ones(D, dtype=torch.bool)) or True
         assert bool((gW[~fired.to(DEV)] == 0).all())                 # silent features: zero gradient rows
         opt.step(project=True)
         opt.zero_grad()
