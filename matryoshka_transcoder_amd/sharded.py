@@ -1,0 +1,253 @@
+"""Dictionary-sharded transcoder: one process per GPU, features split over the ranks
+(BASELINE.json configs 3-5).  The reference has no multi-device code; this is the
+MI355X layout of the same math, checked against the single-GPU path.
+
+Layout.  Every prefix GROUP is cut into `world` equal contiguous slices and rank r owns slice r of
+each group, so each rank holds 1/world of every nesting level (a plain contiguous split would put
+all coarse prefixes on rank 0) and its local cumulative prefixes are the global ones / world.
+Rank r owns W_enc[:, S_r], b_enc[S_r], W_dec[S_r, :], their Adam moments and the dead counters of
+S_r; b_dec, the threshold and the batch are replicated.
+
+Step (RCCL through torch.distributed; every exchange is a real data dependency of the algorithm):
+  1. local encoder GEMM on the slice;
+  2. global TopK threshold: per radix level, local 4096-bin histogram -> all-reduce(sum) (16 KiB)
+     -> identical scan on every rank; ties at tau are granted in (row, rank, feature) order from an
+     all-gather of per-row tie counts ([world, B] ints);
+  3. local sparse decode into bias-free per-prefix partial sums -> all-reduce(sum) of
+     [G, B, A_t] fp32 -> every rank finishes x_hat, losses, FVU and g identically;
+  4. backward and Adam are local to the shard (no gradient all-reduce); db_dec is identical
+     everywhere because g is.
+`state_dict()` gathers to the reference's layout; `load_state_dict()` scatters from it.
+"""
+from __future__ import annotations
+
+from typing import List
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from .engine import HotPath, Selection, _p, _stream, check
+from .training import FusedAdam
+from .transcoder import MatryoshkaTranscoder, _feature_major
+
+import ctypes as C
+
+
+class ShardLayout:
+    """Pure index arithmetic of the feature partition (host side, no device work)."""
+
+    def __init__(self, prefix_sizes: List[int], world: int, rank: int):
+        groups = [b - a for a, b in zip([0] + list(prefix_sizes[:-1]), prefix_sizes)]
+        for g in groups:
+            if g % (8 * world):
+                raise _lib.MtcError(f"every prefix group must be a multiple of 8*world={8 * world}; groups={groups}")
+        self.world, self.rank = world, rank
+        self.global_prefix = list(prefix_sizes)
+        self.groups = groups
+        self.local_groups = [g // world for g in groups]
+        self.local_prefix, run = [], 0
+        for g in self.local_groups:
+            run += g
+            self.local_prefix.append(run)
+        self.D = prefix_sizes[-1]
+        self.D_local = run
+
+    def global_index(self, rank: int) -> torch.Tensor:
+        """Global feature id of every local feature of `rank`, in local order."""
+        parts, start = [], 0
+        for g, lg in zip(self.groups, self.local_groups):
+            parts.append(torch.arange(start + rank * lg, start + (rank + 1) * lg))
+            start += g
+        return torch.cat(parts)
+
+    def owner_permutation(self) -> torch.Tensor:
+        """perm such that cat([shard_0, ..., shard_{w-1}])[perm] is in global feature order."""
+        order = torch.cat([self.global_index(r) for r in range(self.world)])
+        return torch.argsort(order)
+
+
+def tie_before(all_eq: torch.Tensor, rank: int) -> torch.Tensor:
+    """all_eq [world, B] = per-row counts of activations equal to tau on every rank.  Ties are granted
+    in (row, rank) order; returns, for `rank`, how many ties precede each of its rows."""
+    per_row = all_eq.sum(0)
+    earlier_rows = torch.cumsum(per_row, 0) - per_row
+    earlier_ranks = all_eq[:rank].sum(0) if rank > 0 else torch.zeros_like(per_row)
+    return (earlier_rows + earlier_ranks).to(torch.int32)
+
+
+class _Comm:
+    """torch.distributed on device tensors.  backend "nccl" is RCCL on ROCm; with "gloo" (tests)
+    device tensors are staged through the host."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.staged = dist.get_backend(group) == "gloo"
+
+    def all_reduce(self, t: torch.Tensor, op=dist.ReduceOp.SUM) -> torch.Tensor:
+        if self.staged and t.is_cuda:
+            h = t.cpu()
+            dist.all_reduce(h, op=op, group=self.group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=op, group=self.group)
+        return t
+
+    def all_gather(self, t: torch.Tensor) -> torch.Tensor:
+        if self.staged and t.is_cuda:
+            h = t.cpu()
+            out = [torch.empty_like(h) for _ in range(self.world)]
+            dist.all_gather(out, h, group=self.group)
+            return torch.stack(out).to(t.device)
+        t = t.contiguous()
+        out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, t, group=self.group)
+        return out.reshape((self.world,) + tuple(t.shape))
+
+
+class ShardedMatryoshkaTranscoder(MatryoshkaTranscoder):
+    def __init__(self, cfg: dict, group=None):
+        if not dist.is_initialized():
+            raise _lib.MtcError("ShardedMatryoshkaTranscoder needs an initialised torch.distributed process group")
+        self.comm_group = group
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        layout = ShardLayout(list(cfg["prefix_sizes"]), world, rank)
+        # full reference init on the host (same RNG stream on every rank), then keep only the shard
+        full_cfg = dict(cfg, device="cpu")
+        super().__init__(full_cfg)
+        self.config = cfg
+        self.layout = layout
+        idx = layout.global_index(rank)
+        with torch.no_grad():
+            b_enc, W_enc, W_dec = self.b_enc.data[idx], self.W_enc.data[:, idx], self.W_dec.data[idx]
+        self.b_enc = torch.nn.Parameter(b_enc.contiguous())
+        self.W_enc = torch.nn.Parameter(_feature_major(W_enc))
+        self.W_dec = torch.nn.Parameter(W_dec.contiguous())
+        self._cnt = torch.zeros(layout.D_local)
+        self.prefix_sizes = list(cfg["prefix_sizes"])            # public attributes stay global
+        self.local_prefix_sizes = layout.local_prefix
+        self._hp = None
+        self.to(cfg["device"])
+        self._cnt = self._cnt.to(cfg["device"])
+        self.comm = _Comm(group)
+
+    def hot_path(self) -> HotPath:
+        if self._hp is None or self._hp.dtype != self.dtype:
+            self._hp = HotPath(self.source_act_size, self.target_act_size, self.local_prefix_sizes, self.dtype,
+                               bool(self.config.get("input_unit_norm", False)))
+        return self._hp
+
+    # ------------------------------------------------------------------ step 2: global select
+    def _select(self, hp, d, acts, training: bool) -> Selection:
+        if not training:
+            return hp.select_threshold(d, acts, self.threshold)
+        lib, s, dev = hp.lib, _stream(), acts.device
+        B = d.B
+        k_total = int(self.config["top_k"]) * B
+        st = torch.empty(16, dtype=torch.int32, device=dev)
+        check(lib.mtc_select_init(_p(st), k_total, s), "mtc_select_init")
+        for level in range(lib.mtc_select_levels(C.byref(d))):
+            hist = torch.zeros(4096, dtype=torch.int32, device=dev)
+            check(lib.mtc_select_hist(C.byref(d), _p(acts), level, _p(st), _p(hist), s), "mtc_select_hist")
+            self.comm.all_reduce(hist)
+            check(lib.mtc_select_scan(C.byref(d), level, _p(hist), _p(st), s), "mtc_select_scan")
+        row_gt = torch.empty(B, dtype=torch.int32, device=dev)
+        row_eq = torch.empty(B, dtype=torch.int32, device=dev)
+        check(lib.mtc_select_count(C.byref(d), _p(acts), _p(st), None, _p(row_gt), _p(row_eq), s), "mtc_select_count")
+        before = tie_before(self.comm.all_gather(row_eq), self.comm.rank).contiguous()
+        row_ptr = torch.empty(B + 1, dtype=torch.int32, device=dev)
+        tie_take = torch.empty(B, dtype=torch.int32, device=dev)
+        check(lib.mtc_select_offsets(C.byref(d), _p(row_gt), _p(row_eq), _p(before), _p(st), _p(row_ptr), _p(tie_take), s),
+              "mtc_select_offsets")
+        cap = max(k_total, 1)                       # a single rank can hold at most all k*B entries
+        col_idx = torch.empty(cap, dtype=torch.int32, device=dev)
+        vals = torch.empty(cap, dtype=self.dtype, device=dev)
+        check(lib.mtc_select_fill(C.byref(d), _p(acts), _p(st), None, _p(row_ptr), _p(tie_take), _p(col_idx), _p(vals), s),
+              "mtc_select_fill")
+        sel = Selection(st, row_ptr, col_idx, vals)
+        # threshold EMA (a5) needs the GLOBAL smallest selected value and whether anything was selected
+        glob = torch.stack([st[6].to(torch.int64) & 0xffffffff, -st[7].to(torch.int64)])
+        self.comm.all_reduce(glob, op=dist.ReduceOp.MIN)
+        st_ema = st.clone()
+        st_ema[6] = torch.where(glob[0] >= 2 ** 31, glob[0] - 2 ** 32, glob[0]).to(torch.int32)
+        st_ema[7] = (-glob[1]).clamp(max=2 ** 31 - 1).to(torch.int32)          # max over ranks of the local nnz
+        hp.threshold_ema(d, Selection(st_ema, row_ptr, col_idx, vals), self.threshold)
+        return sel
+
+    # ------------------------------------------------------------------ step 3: decode + losses
+    def _decode_and_losses(self, hp, d, sel, acts, W_dec, b_dec, x_target, mean, std, need_grad, aux_active):
+        if aux_active:
+            raise _lib.MtcError("dead features exist, but the auxiliary loss is not built for the feature-sharded "
+                                "model yet (single-GPU MatryoshkaTranscoder has it)")
+        cfg = self.config
+        lib, s, dev = hp.lib, _stream(), x_target.device
+        B, A_t, G = d.B, hp.A_t, d.G
+        partial = torch.empty(G, B, A_t, dtype=torch.float32, device=dev)
+        abs_rows = torch.empty(B, dtype=torch.float32, device=dev)
+        check(lib.mtc_decode_partial(C.byref(d), _p(sel.row_ptr), _p(sel.col_idx), _p(sel.vals), _p(W_dec), _p(partial),
+                                     _p(abs_rows), s), "mtc_decode_partial")
+        self.comm.all_reduce(partial)
+        nnz_abs = torch.stack([sel.state[7].to(torch.float32), abs_rows.sum()])
+        self.comm.all_reduce(nnz_abs)
+        x_hat = torch.empty(B, A_t, dtype=self.dtype, device=dev)
+        g = torch.empty(B, A_t, dtype=torch.float32, device=dev)
+        row_stats = torch.zeros(G + 4, B, dtype=torch.float32, device=dev)
+        check(lib.mtc_decode_finish(C.byref(d), _p(partial), _p(b_dec), _p(x_target), _p(mean), _p(std), _p(x_hat), _p(g),
+                                    _p(row_stats), None, s), "mtc_decode_finish")
+        l1_term = float(cfg["l1_coeff"]) / (B * self.total_dict_size)
+        d_vals = hp.decode_bwd_vals(d, sel, W_dec, g, l1_term) if need_grad else None
+        scalars = hp.reduce_scalars(d, row_stats, sel, self.total_dict_size, float(cfg["l1_coeff"]),
+                                    float(cfg["aux_penalty"]), nnz_abs_override=nnz_abs)
+        return x_hat, g, d_vals, row_stats, scalars, None
+
+    # ------------------------------------------------------------------ checkpoints in the reference layout
+    def _gather_features(self, local: torch.Tensor, dim: int) -> torch.Tensor:
+        parts = self.comm.all_gather(local.movedim(dim, 0).contiguous())      # [world, D_local, ...]
+        flat = parts.reshape((-1,) + tuple(parts.shape[2:]))
+        return flat[self.layout.owner_permutation().to(flat.device)].movedim(0, dim)
+
+    def state_dict(self, *args, **kwargs):
+        """Collective: every rank returns the full reference-layout state dict."""
+        local = super().state_dict(*args, **kwargs)
+        out = type(local)()
+        for k, v in local.items():
+            name = k.split(".")[-1]
+            if name in ("b_enc", "W_dec"):
+                out[k] = self._gather_features(v.detach(), 0)
+            elif name == "W_enc":
+                out[k] = self._gather_features(v.detach(), 1).contiguous()
+            else:
+                out[k] = v
+        return out
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        idx = self.layout.global_index(self.comm.rank)
+        local = {}
+        for k, v in state_dict.items():
+            if k in ("b_enc", "W_dec"):
+                local[k] = v[idx.to(v.device)]
+            elif k == "W_enc":
+                local[k] = v[:, idx.to(v.device)]
+            else:
+                local[k] = v
+        return super().load_state_dict(local, strict=strict, **kw)
+
+    def gathered_dead_counters(self) -> torch.Tensor:
+        return self._gather_features(self._cnt, 0)
+
+    def encode(self, x_source):
+        """Dense [.., D] features in GLOBAL feature order (collective)."""
+        shape = x_source.shape
+        local = super().encode(x_source)
+        full = self._gather_features(local.reshape(-1, local.shape[-1]), 1)
+        return full.reshape(shape[:-1] + (self.total_dict_size,))
+
+    def decode(self, acts_topk):
+        raise _lib.MtcError("decode() of a dense global feature tensor is not built for the sharded model; gather the "
+                            "state_dict into a single-GPU MatryoshkaTranscoder for inference")
+
+
+class ShardedFusedAdam(FusedAdam):
+    """FusedAdam over the local shard; nothing to exchange (b_dec's gradient is identical on all ranks)."""

@@ -69,6 +69,7 @@ class MatryoshkaTranscoder(nn.Module):
         self.prefix_indices = [0] + prefix_sizes
         self.active_prefixes = len(prefix_sizes)
         D = prefix_sizes[-1]
+        self.total_dict_size = D
         self.source_act_size = cfg.get("source_act_size", cfg.get("act_size"))
         self.target_act_size = cfg.get("target_act_size", cfg.get("act_size"))
 
@@ -213,22 +214,28 @@ class MatryoshkaTranscoder(nn.Module):
         hp.build_csc(d, sel, self._cnt)                              # counters BEFORE aux (sae.py:233,242)
         self._dead_check_in -= 1
         aux_active = self._aux_may_be_active()
-        l1_term = float(cfg["l1_coeff"]) / (B * hp.D)
-        W_dec_c = W_dec.contiguous()
+        x_hat, g, d_vals, row_stats, scalars, aux = self._decode_and_losses(
+            hp, d, sel, acts, W_dec.contiguous(), b_dec.contiguous(), x_target, mean, std, need_grad, aux_active)
+        from .engine import ForwardResult
+        return ForwardResult(B=B, desc=d, x_norm=xn, mean=mean, std=std, acts=None, sel=sel, x_hat=x_hat,
+                             g=g if need_grad else None, d_vals=d_vals, row_stats=row_stats, scalars=scalars, aux=aux)
+
+    def _decode_and_losses(self, hp, d, sel, acts, W_dec, b_dec, x_target, mean, std, need_grad, aux_active):
+        """a6-a10: decode + losses (+ aux).  Overridden by the feature-sharded model."""
+        cfg = self.config
+        l1_term = float(cfg["l1_coeff"]) / (d.B * self.total_dict_size)
         x_hat, g, row_stats, _, d_vals = hp.decode(
-            d, sel, W_dec_c, b_dec.contiguous(), x_target, mean, std, want_g=need_grad or aux_active,
+            d, sel, W_dec, b_dec, x_target, mean, std, want_g=need_grad or aux_active,
             want_dvals=need_grad and not aux_active, l1_term=l1_term)
         aux = None
         aux_rows = None
         if aux_active:
-            aux, aux_rows = self._run_aux(hp, d, acts, sel, W_dec_c, x_target, x_hat, g, need_grad, l1_term)
+            aux, aux_rows = self._run_aux(hp, d, acts, sel, W_dec, x_target, x_hat, g, need_grad, l1_term)
             if need_grad:
-                d_vals = hp.decode_bwd_vals(d, sel, W_dec_c, g, l1_term)
-        scalars = hp.reduce_scalars(d, row_stats, sel, hp.D, float(cfg["l1_coeff"]), float(cfg["aux_penalty"]),
-                                    aux_rows=aux_rows)
-        from .engine import ForwardResult
-        return ForwardResult(B=B, desc=d, x_norm=xn, mean=mean, std=std, acts=None, sel=sel, x_hat=x_hat,
-                             g=g if need_grad else None, d_vals=d_vals, row_stats=row_stats, scalars=scalars, aux=aux)
+                d_vals = hp.decode_bwd_vals(d, sel, W_dec, g, l1_term)
+        scalars = hp.reduce_scalars(d, row_stats, sel, self.total_dict_size, float(cfg["l1_coeff"]),
+                                    float(cfg["aux_penalty"]), aux_rows=aux_rows)
+        return x_hat, g, d_vals, row_stats, scalars, aux
 
     def _run_aux(self, hp, d, acts, sel, W_dec, x_target, x_hat, g, need_grad, l1_term):
         cfg = self.config

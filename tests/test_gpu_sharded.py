@@ -1,0 +1,108 @@
+"""Feature-sharded step (2 ranks sharing the one GPU of the test box, gloo as the transport) against
+the single-GPU path on the same weights and batches: losses, FVU, threshold, counters, and the
+gathered weights after 3 optimizer steps."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _cfg(dt, unit):
+    return dict(seed=49, prefix_sizes=[256, 768, 1792, 4096], act_size=256, top_k=32, top_k_aux=64,
+                aux_penalty=1 / 32, n_batches_to_dead=20, l1_coeff=1e-3, dtype=dt, device="cuda:0",
+                input_unit_norm=unit, lr=3e-4, beta1=0.9, beta2=0.99)
+
+
+def _batches(dt, n=3, B=192):
+    out = []
+    for i in range(n):
+        g = torch.Generator("cpu").manual_seed(1000 + i)
+        out.append((torch.randn(B, 256, generator=g).to(dt), torch.randn(B, 256, generator=g).to(dt)))
+    return out
+
+
+def _train(model, opt, batches):
+    log = []
+    for xs, xt in batches:
+        out = model(xs.cuda(), xt.cuda())
+        out["loss"].backward()
+        opt.step(project=True)
+        opt.zero_grad()
+        log.append({k: float(v.detach().float()) for k, v in out.items() if v.dim() == 0})
+    return log
+
+
+def _worker(rank, world, port, dt_name, unit, ret):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from matryoshka_transcoder_amd.sharded import ShardedFusedAdam, ShardedMatryoshkaTranscoder
+        dt = getattr(torch, dt_name)
+        cfg = _cfg(dt, unit)
+        m = ShardedMatryoshkaTranscoder(cfg)
+        opt = ShardedFusedAdam(m, lr=cfg["lr"], betas=(cfg["beta1"], cfg["beta2"]))
+        log = _train(m, opt, _batches(dt))
+        sd = {k: v.cpu() for k, v in m.state_dict().items()}
+        cnt = m.gathered_dead_counters().cpu()
+        if rank == 0:
+            ret["log"] = log
+            ret["sd"] = sd
+            ret["cnt"] = cnt
+        ret[rank] = "ok"
+        dist.destroy_process_group()
+    except Exception:  # noqa: BLE001
+        import traceback
+        ret[rank] = traceback.format_exc()
+
+
+@pytest.mark.parametrize("dt_name,unit", [("float32", False), ("bfloat16", True)])
+def test_sharded_matches_single_gpu(dt_name, unit, gpu_lib):
+    from matryoshka_transcoder_amd.training import FusedAdam
+    from matryoshka_transcoder_amd.transcoder import MatryoshkaTranscoder
+    dt = getattr(torch, dt_name)
+    cfg = _cfg(dt, unit)
+    ref = MatryoshkaTranscoder(cfg)
+    ref_log = _train(ref, FusedAdam(ref, lr=cfg["lr"], betas=(cfg["beta1"], cfg["beta2"])), _batches(dt))
+    ref_sd = {k: v.cpu() for k, v in ref.state_dict().items()}
+    ref_cnt = ref.num_batches_not_active.cpu()
+    torch.cuda.synchronize()
+
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, dt_name, unit, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(170)
+    for r in range(2):
+        assert ret.get(r) == "ok", ret.get(r)
+    f32 = dt == torch.float32
+    rtol = 1e-5 if f32 else 2e-2
+    for a, b in zip(ret["log"], ref_log):
+        for k in b:
+            assert abs(a[k] - b[k]) <= rtol * abs(b[k]) + 1e-7, (k, a[k], b[k])
+    assert torch.equal(ret["cnt"], ref_cnt) or not f32
+    for k, v in ref_sd.items():
+        got = ret["sd"][k]
+        assert got.shape == v.shape
+        if f32:
+            assert torch.allclose(got, v, rtol=0, atol=1e-2 * cfg["lr"] + 1e-7), k
+        else:
+            ulp = (v.float().abs() * 2 ** -7).clamp_min(2 ** -14)
+            n_off = int(((got.float() - v.float()).abs() > ulp).sum())
+            assert n_off <= 0.03 * v.numel() + 8, (k, n_off, v.numel())
