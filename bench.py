@@ -97,7 +97,7 @@ def stage_times(tc, opt, pool, reps=5):
             return r
         setattr(hp, name, inner)
 
-    for n in ("normalize", "encode", "select_topk", "threshold_ema", "build_csc", "decode", "reduce_scalars",
+    for n in ("normalize", "encode", "select_topk", "threshold_ema", "build_csc", "decode", "decode_bwd_vals", "reduce_scalars",
               "backward", "unitnorm_adam", "adam_flat"):
         wrap(n)
     acc = {}

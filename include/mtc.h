@@ -115,13 +115,13 @@ int mtc_threshold_ema(const mtc_desc* d, const mtc_select_state* st, void* thres
  * de-normalised (sae.py:149-153) and rounded to the model dtype; fused per-row partials of the
  * per-prefix squared error (losses sae.py:236, FVU config.py:222-232) and of sum(x_t), sum(x_t^2).
  *   x_hat     [B][A_t] model dtype (last prefix)          row_stats [G+4][B] float:
- *   g         [B][A_t] float, = 2/(B*A_t) * (x_hat-x_t) * std_row    rows 0..G-1  SSE of prefix i
+ *   g         [B][A_t] model dtype, = 2/(B*A_t)*(x_hat-x_t)*std_row  rows 0..G-1  SSE of prefix i
  *             (NULL = forward only)                                  row G sum x_t, G+1 sum x_t^2,
  *   recons    optional [G][B][A_t] model dtype (every prefix)        row G+2 sum |a|, G+3 unused
  * Pure decode (a15, sae.py:389-406): x_target = g = row_stats = d_vals = NULL. */
 int mtc_decode_fwd(const mtc_desc* d, const int32_t* row_ptr, const int32_t* col_idx,
                    const void* vals, const void* W_dec, const void* b_dec, const void* x_target,
-                   const void* mean, const void* std, void* x_hat, float* g, float* row_stats,
+                   const void* mean, const void* std, void* x_hat, void* g, float* row_stats,
                    void* recons, float* d_vals /* NULL, or [nnz]: fused a11 sweep, see
                    mtc_decode_bwd_vals */, float l1_term, void* stream);
 
@@ -132,7 +132,7 @@ int mtc_decode_partial(const mtc_desc* d, const int32_t* row_ptr, const int32_t*
                        float* abs_rows /* [B] sum |a| of the local entries, or NULL */, void* stream);
 int mtc_decode_finish(const mtc_desc* d, const float* partial, const void* b_dec,
                       const void* x_target, const void* mean, const void* std, void* x_hat,
-                      float* g, float* row_stats, void* recons, void* stream);
+                      void* g, float* row_stats, void* recons, void* stream);
 
 /* a8/a10/a14  scalar epilogue: reduces row_stats (and the optional aux partials) to the
  * reference's output scalars without leaving the device.
@@ -149,7 +149,7 @@ int mtc_reduce_scalars(const mtc_desc* d, const float* row_stats, const float* a
 
 /* a11  d a_bj = g_b . W_dec[j] (+ l1_coeff/(B*D)) for every selected entry, CSR order. */
 int mtc_decode_bwd_vals(const mtc_desc* d, const int32_t* row_ptr, const int32_t* col_idx,
-                        const void* W_dec, const float* g, float l1_term, float* d_vals,
+                        const void* W_dec, const void* g, float l1_term, float* d_vals,
                         void* stream);
 
 /* a7  update_inactive_features (sae.py:165-169) + feature-major index of the selection.
@@ -170,10 +170,10 @@ int mtc_build_csc(const mtc_desc* d, const int32_t* row_ptr, const int32_t* col_
  * existing gradient buffers (used for the aux contributions). */
 int mtc_backward_sparse(const mtc_desc* d, const int32_t* col_ptr, const int32_t* csc_row,
                         const int32_t* csc_pos, const void* vals, const float* d_vals,
-                        const float* g, const void* x_norm, const float* scale, void* dW_dec,
+                        const void* g, const void* x_norm, const float* scale, void* dW_dec,
                         void* dW_encT, void* db_enc, int accumulate, void* stream);
 size_t mtc_colsum_workspace_bytes(const mtc_desc* d);
-int mtc_colsum(const mtc_desc* d, const float* g, const float* scale, void* workspace,
+int mtc_colsum(const mtc_desc* d, const void* g, const float* scale, void* workspace,
                size_t workspace_bytes, void* db_dec, int accumulate, void* stream);
 
 /* a12 + a13  make_decoder_weights_and_grad_unit_norm (sae.py:155-163) fused with torch.optim.Adam
@@ -212,7 +212,7 @@ int mtc_aux_fill(const mtc_desc* d, const void* acts, const int32_t* dead_idx,
                  void* stream);
 int mtc_aux_fwd(const mtc_desc* d, const int32_t* row_ptr, const int32_t* col_idx, const void* vals,
                 const void* W_dec, const void* x_target, const void* x_hat, const void* std,
-                float aux_penalty, float* g, float* g_aux, float* aux_rows, float* d_aux_vals,
+                float aux_penalty, void* g, void* g_aux, float* aux_rows, float* d_aux_vals,
                 void* stream);
 
 /* a15 helpers: CSR <-> dense [B][D] in the model dtype (encode returns dense, decode takes it) */

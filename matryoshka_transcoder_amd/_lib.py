@@ -8,7 +8,7 @@ import os
 MTC_F32, MTC_BF16 = 0, 1
 MTC_MAX_PREFIX = 16
 _LIB = None
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmtc.so")
+_LIB_PATH = os.environ.get("MTC_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmtc.so")
 
 
 class MtcError(RuntimeError):

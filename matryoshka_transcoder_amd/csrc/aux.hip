@@ -148,8 +148,8 @@ __global__ __launch_bounds__(256) void aux_fwd_kernel(int B, int A_t, int unit_n
                                                       const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col_idx,
                                                       const void* __restrict__ vals, const void* __restrict__ W_dec,
                                                       const void* __restrict__ x_target, const void* __restrict__ x_hat,
-                                                      const void* __restrict__ std_p, float* __restrict__ g,
-                                                      float* __restrict__ g_aux, float* __restrict__ aux_rows,
+                                                      const void* __restrict__ std_p, void* __restrict__ g,
+                                                      void* __restrict__ g_aux, float* __restrict__ aux_rows,
                                                       float* __restrict__ d_aux_vals) {
     typedef DType<DT> D_;
     typedef typename D_::T T;
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void aux_fwd_kernel(int B, int A_t, int unit_n
             float t[8], h[8], gg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ga[8];
             load8<DT>(x_target, off, t);
             load8<DT>(x_hat, off, h);
-            if (g) load8<MTC_F32>(g, off, gg);
+            if (g) load8<DT>(g, off, gg);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const float e = D_::rnd(acc[c][k]) - (t[k] - h[k]);
@@ -189,8 +189,8 @@ __global__ __launch_bounds__(256) void aux_fwd_kernel(int B, int A_t, int unit_n
                 acc[c][k] = ga[k];                       // acc now holds g_aux for the second sweep
                 gg[k] += ga[k] * stdv;
             }
-            if (g) store8<MTC_F32>(g, off, gg);
-            if (g_aux) store8<MTC_F32>(g_aux, off, ga);
+            if (g) store8<DT>(g, off, gg);
+            if (g_aux) store8<DT>(g_aux, off, ga);
         }
     }
     sse = wave_sum(sse);
@@ -250,7 +250,7 @@ extern "C" int mtc_aux_fill(const mtc_desc* d, const void* acts, const int32_t* 
 
 extern "C" int mtc_aux_fwd(const mtc_desc* d, const int32_t* row_ptr, const int32_t* col_idx, const void* vals,
                            const void* W_dec, const void* x_target, const void* x_hat, const void* std, float aux_penalty,
-                           float* g, float* g_aux, float* aux_rows, float* d_aux_vals, void* stream) {
+                           void* g, void* g_aux, float* aux_rows, float* d_aux_vals, void* stream) {
     if (check_desc(d, "mtc_aux_fwd")) return -1;
     MTC_REQUIRE(row_ptr && col_idx && vals && W_dec && x_target && x_hat && aux_rows, "mtc_aux_fwd: null pointer");
     MTC_REQUIRE(!d->unit_norm || std, "mtc_aux_fwd: unit_norm needs std");

@@ -2,13 +2,14 @@
 // feature-major index it needs; dead-feature counters (sae.py:165-169).
 //
 // The selected entries are re-indexed by FEATURE (CSC).  One wavefront per feature j then builds
-//     dW_dec[j]  = sum_b a_bj  * g_b        (gathers rows of g,      [B][A_t] fp32)
+//     dW_dec[j]  = sum_b a_bj  * g_b        (gathers rows of g,      [B][A_t] model dtype)
 //     dW_encT[j] = sum_b da_bj * x_b        (gathers rows of x_norm, [B][A_s] model dtype)
 // in registers and writes each gradient row exactly once -- no float atomics, rows of silent
 // features are written as zeros, so the dense gradient the optimizer expects costs no extra pass.
-// The gathered operands (g: B*A_t*4 B, x: B*A_s*s B) are small enough to live in L2 / Infinity
-// Cache; algorithmic bytes = nnz*(A_t*4 + A_s*s) gathered + D*(A_t + A_s)*s written.
+// The gathered operands (g: B*A_t*s B, x: B*A_s*s B) are small enough to live in L2 / Infinity
+// Cache; algorithmic bytes = nnz*(A_t + A_s)*s gathered + D*(A_t + A_s)*s written.
 #include "common.hpp"
+#include "rowops.hpp"
 
 namespace mtc {
 
@@ -121,19 +122,20 @@ __global__ __launch_bounds__(256) void csc_sort_long_kernel(int D, int B, const 
 
 // ---------------------------------------------------------------- gradient rows
 // out[j][:] = scale * sum_{e in feature j} coef[csc_pos[e]] * src[csc_row[e]][:]
-// SRC_DT: dtype of the gathered rows; OUT_DT: gradient dtype; COEF_DT: dtype of coef (vals are model dtype,
-// d_vals fp32).  bias_out (optional) = scale * sum coef.
-template <int SRC_DT, int OUT_DT, int COEF_DT, int NC>
-__global__ __launch_bounds__(256) void grad_rows_kernel(int D, int A, const int32_t* __restrict__ col_ptr,
-                                                        const int32_t* __restrict__ csc_row, const int32_t* __restrict__ csc_pos,
-                                                        const void* __restrict__ coef, const void* __restrict__ src,
-                                                        const float* __restrict__ scale_p, void* __restrict__ out,
-                                                        void* __restrict__ bias_out, int accumulate) {
-    typedef DType<OUT_DT> O_;
-    const int lane = threadIdx.x & 63;
+// DT: model dtype of src and out; COEF_DT: dtype of coef (vals are model dtype, d_vals fp32).
+// bias_out (optional) = scale * sum coef.
+template <int DT, int COEF_DT, int NC>
+__global__ __launch_bounds__(256, (NC <= 5 ? 4 : 2)) void grad_rows_kernel(
+    int D, int A, const int32_t* __restrict__ col_ptr, const int32_t* __restrict__ csc_row,
+    const int32_t* __restrict__ csc_pos, const void* __restrict__ coef, const void* __restrict__ src,
+    const float* __restrict__ scale_p, void* __restrict__ out, void* __restrict__ bias_out, int accumulate) {
+    typedef DType<DT> O_;
+    RowCtx<DT, NC> rc;
+    rc.lane = threadIdx.x & 63;
+    rc.nch = A >> 3;
+    const int lane = rc.lane;
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= D) return;
-    const int nch = A >> 3;
     const float scale = scale_p ? *scale_p : 1.f;
     float acc[NC][8];
 #pragma unroll
@@ -151,35 +153,22 @@ __global__ __launch_bounds__(256) void grad_rows_kernel(int D, int A, const int3
             my_c = DType<COEF_DT>::ld(reinterpret_cast<const typename DType<COEF_DT>::T*>(coef) + pos);
         }
         csum += my_c;
-        for (int i = 0; i < nb; ++i) {
-            const int r = __builtin_amdgcn_readlane(my_row, i);
-            const float a = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_c), i));
-            const size_t rowoff = (size_t)r * A;
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                if (lane + 64 * c < nch) {
-                    float w[8];
-                    load8<SRC_DT>(src, rowoff + (size_t)(lane + 64 * c) * 8, w);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) acc[c][k] = fmaf(a, w[k], acc[c][k]);
-                }
-            }
-        }
+        accumulate_run<DT, NC>(rc, src, A, my_row, my_c, 0, nb, acc);
     }
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-        if (lane + 64 * c < nch) {
-            const size_t off = (size_t)j * A + (size_t)(lane + 64 * c) * 8;
+        if (rc.valid(c)) {
+            const size_t off = (size_t)j * A + rc.off(c);
             float o[8];
             if (accumulate) {
-                load8<OUT_DT>(out, off, o);
+                load8<DT>(out, off, o);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) o[k] = O_::rnd(o[k] + scale * acc[c][k]);
             } else {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) o[k] = scale * acc[c][k];
             }
-            store8<OUT_DT>(out, off, o);
+            store8<DT>(out, off, o);
         }
     }
     if (bias_out) {
@@ -192,14 +181,16 @@ __global__ __launch_bounds__(256) void grad_rows_kernel(int D, int A, const int3
 }
 
 // ---------------------------------------------------------------- db_dec = sum_b g_b
-__global__ __launch_bounds__(256) void colsum_partial_kernel(int B, int A, const float* __restrict__ g, int rows_per_slab,
+template <int DT>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(int B, int A, const void* __restrict__ g, int rows_per_slab,
                                                              float* __restrict__ partial) {
+    typedef typename DType<DT>::T T;
     const int col = blockIdx.x * 256 + threadIdx.x;
     const int slab = blockIdx.y;
     if (col >= A) return;
     const int r0 = slab * rows_per_slab, r1 = min(B, r0 + rows_per_slab);
     float s = 0.f;
-    for (int r = r0; r < r1; ++r) s += g[(size_t)r * A + col];
+    for (int r = r0; r < r1; ++r) s += DType<DT>::ld(reinterpret_cast<const T*>(g) + (size_t)r * A + col);
     partial[(size_t)slab * A + col] = s;
 }
 template <int DT>
@@ -220,7 +211,6 @@ __global__ __launch_bounds__(256) void colsum_finish_kernel(int A, int slabs, co
 
 using namespace mtc;
 
-static int nc_for(int A) { return ((A >> 3) + 63) / 64; }
 static int long_sort_blocks() { return 64; }
 
 extern "C" size_t mtc_csc_workspace_bytes(const mtc_desc* d) {
@@ -254,34 +244,33 @@ extern "C" int mtc_build_csc(const mtc_desc* d, const int32_t* row_ptr, const in
     return check_launch("mtc_build_csc");
 }
 
-#define LAUNCH_GRAD(SRC, OUT, COEF, ncv)                                                                             \
+#define LAUNCH_GRAD(DTV, COEF, ncv)                                                                                  \
     do {                                                                                                             \
         const int nc_ = (ncv);                                                                                       \
-        if (nc_ <= 1) hipLaunchKernelGGL((grad_rows_kernel<SRC, OUT, COEF, 1>), grid, block, 0, s, D, A, col_ptr, csc_row, csc_pos, coef, src, scale, out, bias_out, accumulate); \
-        else if (nc_ <= 2) hipLaunchKernelGGL((grad_rows_kernel<SRC, OUT, COEF, 2>), grid, block, 0, s, D, A, col_ptr, csc_row, csc_pos, coef, src, scale, out, bias_out, accumulate); \
-        else if (nc_ <= 3) hipLaunchKernelGGL((grad_rows_kernel<SRC, OUT, COEF, 3>), grid, block, 0, s, D, A, col_ptr, csc_row, csc_pos, coef, src, scale, out, bias_out, accumulate); \
-        else if (nc_ <= 5) hipLaunchKernelGGL((grad_rows_kernel<SRC, OUT, COEF, 5>), grid, block, 0, s, D, A, col_ptr, csc_row, csc_pos, coef, src, scale, out, bias_out, accumulate); \
-        else if (nc_ <= 7) hipLaunchKernelGGL((grad_rows_kernel<SRC, OUT, COEF, 7>), grid, block, 0, s, D, A, col_ptr, csc_row, csc_pos, coef, src, scale, out, bias_out, accumulate); \
-        else if (nc_ <= 9) hipLaunchKernelGGL((grad_rows_kernel<SRC, OUT, COEF, 9>), grid, block, 0, s, D, A, col_ptr, csc_row, csc_pos, coef, src, scale, out, bias_out, accumulate); \
-        else hipLaunchKernelGGL((grad_rows_kernel<SRC, OUT, COEF, 16>), grid, block, 0, s, D, A, col_ptr, csc_row, csc_pos, coef, src, scale, out, bias_out, accumulate); \
+        if (nc_ <= 1) hipLaunchKernelGGL((grad_rows_kernel<DTV, COEF, 1>), grid, block, 0, s, D, A, col_ptr, csc_row, csc_pos, coef, src, scale, out, bias_out, accumulate); \
+        else if (nc_ <= 2) hipLaunchKernelGGL((grad_rows_kernel<DTV, COEF, 2>), grid, block, 0, s, D, A, col_ptr, csc_row, csc_pos, coef, src, scale, out, bias_out, accumulate); \
+        else if (nc_ <= 3) hipLaunchKernelGGL((grad_rows_kernel<DTV, COEF, 3>), grid, block, 0, s, D, A, col_ptr, csc_row, csc_pos, coef, src, scale, out, bias_out, accumulate); \
+        else if (nc_ <= 5) hipLaunchKernelGGL((grad_rows_kernel<DTV, COEF, 5>), grid, block, 0, s, D, A, col_ptr, csc_row, csc_pos, coef, src, scale, out, bias_out, accumulate); \
+        else if (nc_ <= 7) hipLaunchKernelGGL((grad_rows_kernel<DTV, COEF, 7>), grid, block, 0, s, D, A, col_ptr, csc_row, csc_pos, coef, src, scale, out, bias_out, accumulate); \
+        else if (nc_ <= 9) hipLaunchKernelGGL((grad_rows_kernel<DTV, COEF, 9>), grid, block, 0, s, D, A, col_ptr, csc_row, csc_pos, coef, src, scale, out, bias_out, accumulate); \
+        else hipLaunchKernelGGL((grad_rows_kernel<DTV, COEF, 16>), grid, block, 0, s, D, A, col_ptr, csc_row, csc_pos, coef, src, scale, out, bias_out, accumulate); \
     } while (0)
 
-static void launch_grad_rows(int dtype, bool src_is_g, int D, int A, const int32_t* col_ptr, const int32_t* csc_row,
+static void launch_grad_rows(int dtype, bool coef_is_vals, int D, int A, const int32_t* col_ptr, const int32_t* csc_row,
                              const int32_t* csc_pos, const void* coef, const void* src, const float* scale, void* out,
                              void* bias_out, int accumulate, hipStream_t s) {
     const dim3 grid((D + 3) / 4), block(256);
     const int nc = nc_for(A);
-    if (src_is_g) {          // dW_dec: src = g (fp32), coef = vals (model dtype)
-        if (dtype == MTC_BF16) LAUNCH_GRAD(MTC_F32, MTC_BF16, MTC_BF16, nc);
-        else LAUNCH_GRAD(MTC_F32, MTC_F32, MTC_F32, nc);
-    } else {                 // dW_encT: src = x_norm (model dtype), coef = d_vals (fp32)
-        if (dtype == MTC_BF16) LAUNCH_GRAD(MTC_BF16, MTC_BF16, MTC_F32, nc);
-        else LAUNCH_GRAD(MTC_F32, MTC_F32, MTC_F32, nc);
+    if (dtype == MTC_BF16) {
+        if (coef_is_vals) LAUNCH_GRAD(MTC_BF16, MTC_BF16, nc);     // dW_dec: src = g, coef = vals (model dtype)
+        else LAUNCH_GRAD(MTC_BF16, MTC_F32, nc);                   // dW_encT: src = x_norm, coef = d_vals (fp32)
+    } else {
+        LAUNCH_GRAD(MTC_F32, MTC_F32, nc);
     }
 }
 
 extern "C" int mtc_backward_sparse(const mtc_desc* d, const int32_t* col_ptr, const int32_t* csc_row,
-                                   const int32_t* csc_pos, const void* vals, const float* d_vals, const float* g,
+                                   const int32_t* csc_pos, const void* vals, const float* d_vals, const void* g,
                                    const void* x_norm, const float* scale, void* dW_dec, void* dW_encT, void* db_enc,
                                    int accumulate, void* stream) {
     if (check_desc(d, "mtc_backward_sparse")) return -1;
@@ -296,15 +285,19 @@ extern "C" int mtc_backward_sparse(const mtc_desc* d, const int32_t* col_ptr, co
 
 extern "C" size_t mtc_colsum_workspace_bytes(const mtc_desc* d) { return d ? 32 * (size_t)d->A_t * sizeof(float) : 0; }
 
-extern "C" int mtc_colsum(const mtc_desc* d, const float* g, const float* scale, void* workspace, size_t workspace_bytes,
+extern "C" int mtc_colsum(const mtc_desc* d, const void* g, const float* scale, void* workspace, size_t workspace_bytes,
                           void* db_dec, int accumulate, void* stream) {
     if (check_desc(d, "mtc_colsum")) return -1;
     MTC_REQUIRE(g && workspace && db_dec, "mtc_colsum: null pointer");
     MTC_REQUIRE(workspace_bytes >= mtc_colsum_workspace_bytes(d), "mtc_colsum: workspace too small");
     const int slabs = 32, rows_per = (d->B + slabs - 1) / slabs;
     hipStream_t s = as_stream(stream);
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3((d->A_t + 255) / 256, slabs), dim3(256), 0, s, d->B, d->A_t, g, rows_per,
-                       reinterpret_cast<float*>(workspace));
+    if (d->dtype == MTC_BF16)
+        hipLaunchKernelGGL(colsum_partial_kernel<MTC_BF16>, dim3((d->A_t + 255) / 256, slabs), dim3(256), 0, s, d->B, d->A_t, g,
+                           rows_per, reinterpret_cast<float*>(workspace));
+    else
+        hipLaunchKernelGGL(colsum_partial_kernel<MTC_F32>, dim3((d->A_t + 255) / 256, slabs), dim3(256), 0, s, d->B, d->A_t, g,
+                           rows_per, reinterpret_cast<float*>(workspace));
     if (d->dtype == MTC_BF16)
         hipLaunchKernelGGL(colsum_finish_kernel<MTC_BF16>, dim3((d->A_t + 255) / 256), dim3(256), 0, s, d->A_t, slabs,
                            reinterpret_cast<const float*>(workspace), scale, db_dec, accumulate);

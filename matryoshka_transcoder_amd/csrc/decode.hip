@@ -12,6 +12,10 @@
 #include "common.hpp"
 #include "rowops.hpp"
 
+#ifndef MTC_DECODE_WAVES
+#define MTC_DECODE_WAVES 4     // waves per SIMD the row-gather kernels are register-bounded for (NC <= 5)
+#endif
+
 namespace mtc {
 
 struct DecodeParams {
@@ -53,12 +57,12 @@ __device__ __forceinline__ float boundary_sse(const RowCtx<DT, NC>& rc, const De
 }
 
 template <int DT, int NC>
-__global__ __launch_bounds__(256) void decode_fwd_kernel(DecodeParams p, const int32_t* __restrict__ row_ptr,
+__global__ __launch_bounds__(256, (NC <= 5 ? MTC_DECODE_WAVES : 2)) void decode_fwd_kernel(DecodeParams p, const int32_t* __restrict__ row_ptr,
                                                          const int32_t* __restrict__ col_idx, const void* __restrict__ vals,
                                                          const void* __restrict__ W_dec, const void* __restrict__ b_dec,
                                                          const void* __restrict__ x_target, const void* __restrict__ mean_p,
                                                          const void* __restrict__ std_p, void* __restrict__ x_hat,
-                                                         float* __restrict__ g_out, float* __restrict__ row_stats,
+                                                         void* __restrict__ g_out, float* __restrict__ row_stats,
                                                          void* __restrict__ recons, float* __restrict__ d_vals) {
     typedef DType<DT> D_;
     typedef typename D_::T T;
@@ -131,7 +135,7 @@ __global__ __launch_bounds__(256) void decode_fwd_kernel(DecodeParams p, const i
             }
             store8<DT>(x_hat, (size_t)row * p.A_t + rc.off(c), r);
             if (recons) store8<DT>(reinterpret_cast<T*>(recons) + ((size_t)(p.G - 1) * p.B + row) * p.A_t, rc.off(c), r);
-            if (g_out) store8<MTC_F32>(g_out, (size_t)row * p.A_t + rc.off(c), gg);
+            if (g_out) store8<DT>(g_out, (size_t)row * p.A_t + rc.off(c), gg);
         }
     }
     sse = wave_sum(sse); sx = wave_sum(sx); sxx = wave_sum(sxx); abs_sum = wave_sum(abs_sum);
@@ -154,9 +158,9 @@ __global__ __launch_bounds__(256) void decode_fwd_kernel(DecodeParams p, const i
 
 // standalone d_vals (aux-active and feature-sharded paths: g comes from memory)
 template <int DT, int NC>
-__global__ __launch_bounds__(256) void decode_bwd_vals_kernel(int B, int A_t, const int32_t* __restrict__ row_ptr,
+__global__ __launch_bounds__(256, (NC <= 5 ? MTC_DECODE_WAVES : 2)) void decode_bwd_vals_kernel(int B, int A_t, const int32_t* __restrict__ row_ptr,
                                                               const int32_t* __restrict__ col_idx,
-                                                              const void* __restrict__ W_dec, const float* __restrict__ g,
+                                                              const void* __restrict__ W_dec, const void* __restrict__ g,
                                                               float l1_term, float* __restrict__ d_vals) {
     RowCtx<DT, NC> rc;
     rc.lane = threadIdx.x & 63;
@@ -166,7 +170,7 @@ __global__ __launch_bounds__(256) void decode_bwd_vals_kernel(int B, int A_t, co
     float gr[NC][8];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-        if (rc.valid(c)) load8<MTC_F32>(g, (size_t)row * A_t + rc.off(c), gr[c]);
+        if (rc.valid(c)) load8<DT>(g, (size_t)row * A_t + rc.off(c), gr[c]);
         else
 #pragma unroll
             for (int k = 0; k < 8; ++k) gr[c][k] = 0.f;
@@ -229,7 +233,7 @@ template <int DT>
 __global__ __launch_bounds__(256) void decode_finish_kernel(DecodeParams p, const float* __restrict__ partial,
                                                             const void* __restrict__ b_dec, const void* __restrict__ x_target,
                                                             const void* __restrict__ mean_p, const void* __restrict__ std_p,
-                                                            void* __restrict__ x_hat, float* __restrict__ g_out,
+                                                            void* __restrict__ x_hat, void* __restrict__ g_out,
                                                             float* __restrict__ row_stats, void* __restrict__ recons) {
     typedef DType<DT> D_;
     typedef typename D_::T T;
@@ -266,7 +270,7 @@ __global__ __launch_bounds__(256) void decode_finish_kernel(DecodeParams p, cons
             if (recons) store8<DT>(reinterpret_cast<T*>(recons) + ((size_t)gi * p.B + row) * p.A_t, off, r);
             if (last) {
                 store8<DT>(x_hat, (size_t)row * p.A_t + off, r);
-                if (g_out) store8<MTC_F32>(g_out, (size_t)row * p.A_t + off, gg);
+                if (g_out) store8<DT>(g_out, (size_t)row * p.A_t + off, gg);
             }
         }
         sse = wave_sum(sse);
@@ -348,7 +352,7 @@ using namespace mtc;
 
 extern "C" int mtc_decode_fwd(const mtc_desc* d, const int32_t* row_ptr, const int32_t* col_idx, const void* vals,
                               const void* W_dec, const void* b_dec, const void* x_target, const void* mean,
-                              const void* std, void* x_hat, float* g, float* row_stats, void* recons, float* d_vals,
+                              const void* std, void* x_hat, void* g, float* row_stats, void* recons, float* d_vals,
                               float l1_term, void* stream) {
     if (check_desc(d, "mtc_decode_fwd")) return -1;
     MTC_REQUIRE(row_ptr && col_idx && vals && W_dec && b_dec && x_hat, "mtc_decode_fwd: null pointer");
@@ -363,7 +367,7 @@ extern "C" int mtc_decode_fwd(const mtc_desc* d, const int32_t* row_ptr, const i
 }
 
 extern "C" int mtc_decode_bwd_vals(const mtc_desc* d, const int32_t* row_ptr, const int32_t* col_idx, const void* W_dec,
-                                   const float* g, float l1_term, float* d_vals, void* stream) {
+                                   const void* g, float l1_term, float* d_vals, void* stream) {
     if (check_desc(d, "mtc_decode_bwd_vals")) return -1;
     MTC_REQUIRE(row_ptr && col_idx && W_dec && g && d_vals, "mtc_decode_bwd_vals: null pointer");
     DISPATCH_NC(d->dtype, nc_for(d->A_t), decode_bwd_vals_kernel, dim3((d->B + 3) / 4), dim3(256), as_stream(stream),
@@ -382,7 +386,7 @@ extern "C" int mtc_decode_partial(const mtc_desc* d, const int32_t* row_ptr, con
 }
 
 extern "C" int mtc_decode_finish(const mtc_desc* d, const float* partial, const void* b_dec, const void* x_target,
-                                 const void* mean, const void* std, void* x_hat, float* g, float* row_stats,
+                                 const void* mean, const void* std, void* x_hat, void* g, float* row_stats,
                                  void* recons, void* stream) {
     if (check_desc(d, "mtc_decode_finish")) return -1;
     MTC_REQUIRE(partial && b_dec && x_target && x_hat && row_stats, "mtc_decode_finish: null pointer");

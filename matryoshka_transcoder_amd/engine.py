@@ -169,7 +169,7 @@ class HotPath:
         _need(x_target, "x_target", self.dtype, (d.B, self.A_t))
         dev = x_target.device
         x_hat = torch.empty(d.B, self.A_t, dtype=self.dtype, device=dev)
-        g = torch.empty(d.B, self.A_t, dtype=torch.float32, device=dev) if want_g else None
+        g = torch.empty(d.B, self.A_t, dtype=self.dtype, device=dev) if want_g else None
         row_stats = torch.empty(d.G + 4, d.B, dtype=torch.float32, device=dev)
         recons = torch.empty(d.G, d.B, self.A_t, dtype=self.dtype, device=dev) if want_recons else None
         d_vals = torch.empty(sel.col_idx.numel(), dtype=torch.float32, device=dev) if want_dvals else None
@@ -248,7 +248,7 @@ class HotPath:
         check(lib.mtc_aux_fill(C.byref(d), _p(acts), _p(dead_idx), _p(n_dead), _p(row_tau), _p(row_quota), _p(row_ptr),
                                _p(col_idx), _p(vals), s), "mtc_aux_fill")
         sel = Selection(st, row_ptr, col_idx, vals)
-        g_aux = torch.empty(B, self.A_t, dtype=torch.float32, device=dev)
+        g_aux = torch.empty(B, self.A_t, dtype=self.dtype, device=dev)
         aux_rows = torch.empty(B, dtype=torch.float32, device=dev)
         d_aux = torch.empty(cap, dtype=torch.float32, device=dev) if need_grad else None
         check(lib.mtc_aux_fwd(C.byref(d), _p(row_ptr), _p(col_idx), _p(vals), _p(W_dec), _p(x_target), _p(x_hat), _p(std),

@@ -192,7 +192,7 @@ class ShardedMatryoshkaTranscoder(MatryoshkaTranscoder):
         nnz_abs = torch.stack([sel.state[7].to(torch.float32), abs_rows.sum()])
         self.comm.all_reduce(nnz_abs)
         x_hat = torch.empty(B, A_t, dtype=self.dtype, device=dev)
-        g = torch.empty(B, A_t, dtype=torch.float32, device=dev)
+        g = torch.empty(B, A_t, dtype=self.dtype, device=dev)
         row_stats = torch.zeros(G + 4, B, dtype=torch.float32, device=dev)
         check(lib.mtc_decode_finish(C.byref(d), _p(partial), _p(b_dec), _p(x_target), _p(mean), _p(std), _p(x_hat), _p(g),
                                     _p(row_stats), None, s), "mtc_decode_finish")

@@ -116,7 +116,7 @@ def check_against_oracle(cfg, params, cnt, xs, xt, res, hp):
     _close(res["g"], grads["g"], 1e-4 if f32 else 2e-2, 1e-7 if f32 else 1e-5, "g")
     _close(res["d_vals"][:nnz], grads["d_vals"], 1e-4 if f32 else 2e-2, 1e-7 if f32 else 1e-5, "d_vals")
     dW_dec, dW_encT, db_enc, db_dec = res["grads"]
-    rt, at = (1e-4, 1e-7) if f32 else (2e-2, 2e-5)
+    rt, at = (1e-4, 1e-7) if f32 else (2e-2, 1e-4)
     _close(dW_dec, grads["W_dec"], rt, at, "dW_dec")
     _close(dW_encT.t(), grads["W_enc"], rt, at, "dW_enc")
     _close(db_enc, grads["b_enc"], rt, at, "db_enc")
@@ -263,7 +263,7 @@ def test_aux_path_against_oracle(name, gpu_lib):
     got = set((rows * D + asel.col_idx.cpu()[:n].long()).tolist())
     want = set((aux["rows"] * D + aux["cols"]).tolist())
     assert got == want, "aux selection differs from the oracle's"
-    rt, at = (1e-4, 1e-7) if f32 else (2e-2, 2e-5)
+    rt, at = (1e-4, 1e-7) if f32 else (2e-2, 1e-4)
     _close(out["aux_loss"], o["aux_loss"], rt, at, "aux_loss")
     _close(out["loss"], o["loss"], rt, at, "loss")
     assert out["loss"].dtype == torch.float32 and out["aux_loss"].dtype == torch.float32
