@@ -23,30 +23,65 @@ __global__ __launch_bounds__(256) void csc_count_kernel(int B, const int32_t* __
     for (int e = row_ptr[row] + lane; e < row_ptr[row + 1]; e += 64) atomicAdd(&cnt[col_idx[e]], 1u);
 }
 
-// one workgroup: exclusive scan over D counts -> col_ptr, cursor copy, dead-counter update
-__global__ __launch_bounds__(1024) void csc_scan_kernel(int D, const uint32_t* __restrict__ cnt, int32_t* __restrict__ col_ptr,
-                                                        uint32_t* __restrict__ cursor, float* __restrict__ dead_cnt) {
+// exclusive scan over the D per-feature counts in two small launches (tiles of 4096 features):
+//   A: per-tile totals;  B: each tile adds the totals of the tiles before it, scans itself, writes
+//   col_ptr / cursor, updates the dead counters and lists the features with long segments.
+constexpr int SCAN_TILE = 4096;
+__global__ __launch_bounds__(1024) void csc_tile_sum_kernel(int D, const uint32_t* __restrict__ cnt,
+                                                            uint32_t* __restrict__ tile_sum) {
     __shared__ uint32_t sm[16];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const int per = (D + 1023) / 1024;
-    const int j0 = t * per, j1 = min(D, j0 + per);
-    uint32_t mine = 0;
-    for (int j = j0; j < j1; ++j) mine += cnt[j];
+    const int j0 = blockIdx.x * SCAN_TILE + t * 4;
+    uint32_t v = 0;
+    if (j0 + 3 < D) { const u32x4 q = *reinterpret_cast<const u32x4*>(cnt + j0); v = q[0] + q[1] + q[2] + q[3]; }
+    else for (int i = 0; i < 4; ++i) if (j0 + i < D) v += cnt[j0 + i];
+    v = wave_sum_u32(v);
+    if (lane == 0) sm[w] = v;
+    __syncthreads();
+    if (t == 0) { uint32_t a = 0; for (int i = 0; i < 16; ++i) a += sm[i]; tile_sum[blockIdx.x] = a; }
+}
+
+__global__ __launch_bounds__(1024) void csc_scan_kernel(int D, int n_tiles, const uint32_t* __restrict__ cnt,
+                                                        const uint32_t* __restrict__ tile_sum, int32_t* __restrict__ col_ptr,
+                                                        uint32_t* __restrict__ cursor, float* __restrict__ dead_cnt,
+                                                        int32_t* __restrict__ long_list, uint32_t* __restrict__ n_long) {
+    __shared__ uint32_t sm[16];
+    __shared__ uint32_t s_base;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    if (w == 0) {
+        uint32_t a = 0;
+        for (int i = lane; i < (int)blockIdx.x; i += 64) a += tile_sum[i];
+        a = wave_sum_u32(a);
+        if (lane == 0) s_base = a;
+    }
+    const int j0 = blockIdx.x * SCAN_TILE + t * 4;
+    uint32_t c[4] = {0, 0, 0, 0};
+    if (j0 + 3 < D) { const u32x4 q = *reinterpret_cast<const u32x4*>(cnt + j0); c[0] = q[0]; c[1] = q[1]; c[2] = q[2]; c[3] = q[3]; }
+    else for (int i = 0; i < 4; ++i) if (j0 + i < D) c[i] = cnt[j0 + i];
+    const uint32_t mine = c[0] + c[1] + c[2] + c[3];
     uint32_t inc = mine;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const uint32_t n = __shfl_up(inc, o, 64); if (lane >= o) inc += n; }
     if (lane == 63) sm[w] = inc;
     __syncthreads();
-    uint32_t base = inc - mine, total = 0;
-    for (int i = 0; i < 16; ++i) { if (i < w) base += sm[i]; total += sm[i]; }
-    for (int j = j0; j < j1; ++j) {
-        const uint32_t c = cnt[j];
-        col_ptr[j] = (int32_t)base;
-        cursor[j] = base;
-        if (dead_cnt) dead_cnt[j] = c ? 0.f : dead_cnt[j] + 1.f;
-        base += c;
+    uint32_t base = s_base + inc - mine;
+    for (int i = 0; i < w; ++i) base += sm[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int j = j0 + i;
+        if (j < D) {
+            col_ptr[j] = (int32_t)base;
+            cursor[j] = base;
+            if (dead_cnt) dead_cnt[j] = c[i] ? 0.f : dead_cnt[j] + 1.f;
+            if (c[i] > 64) long_list[atomicAdd(n_long, 1u)] = j;
+            base += c[i];
+        }
     }
-    if (t == 0) col_ptr[D] = (int32_t)total;
+    if (blockIdx.x == n_tiles - 1 && t == 1023) {
+        uint32_t total = s_base;
+        for (int i = 0; i < 16; ++i) total += sm[i];
+        col_ptr[D] = (int32_t)total;
+    }
 }
 
 __global__ __launch_bounds__(256) void csc_fill_kernel(int B, const int32_t* __restrict__ row_ptr,
@@ -83,16 +118,19 @@ __global__ __launch_bounds__(256) void csc_sort_kernel(int D, const int32_t* __r
     // longer segments: csc_sort_long_kernel
 }
 
-// Long segments (> 64 entries): one workgroup per such feature, bitmap-by-row in LDS, then an ordered sweep.
-// rows < B <= 65536.  slot[r] = csc_pos for row r (or -1).
-__global__ __launch_bounds__(256) void csc_sort_long_kernel(int D, int B, const int32_t* __restrict__ col_ptr,
+// Long segments (> 64 entries, listed by the scan): one workgroup per such feature scatters its entries into a
+// per-row slot array (slot[r] = csc_pos for row r, or -1) and sweeps it in row order.  B <= 65536.
+__global__ __launch_bounds__(256) void csc_sort_long_kernel(int B, const int32_t* __restrict__ col_ptr,
+                                                            const int32_t* __restrict__ long_list,
+                                                            const uint32_t* __restrict__ n_long,
                                                             int32_t* __restrict__ csc_row, int32_t* __restrict__ csc_pos,
                                                             int32_t* __restrict__ slot_ws /* gridDim.x * B ints */) {
     __shared__ uint32_t wsum[4];
     int32_t* slot = slot_ws + (size_t)blockIdx.x * B;
-    for (int j = blockIdx.x; j < D; j += gridDim.x) {
+    const int nl = (int)*n_long;
+    for (int li = blockIdx.x; li < nl; li += gridDim.x) {
+        const int j = long_list[li];
         const int s = col_ptr[j], n = col_ptr[j + 1] - s;
-        if (n <= 64) continue;                                  // uniform per block
         for (int r = threadIdx.x; r < B; r += 256) slot[r] = -1;
         __syncthreads();
         for (int i = threadIdx.x; i < n; i += 256) slot[csc_row[s + i]] = csc_pos[s + i];
@@ -215,8 +253,8 @@ static int long_sort_blocks() { return 64; }
 
 extern "C" size_t mtc_csc_workspace_bytes(const mtc_desc* d) {
     if (!d) return 0;
-    // counts[D] + cursor[D] + long-segment row slots
-    return 2 * (size_t)d->D * sizeof(uint32_t) + (size_t)long_sort_blocks() * d->B * sizeof(int32_t);
+    // counts[D] + cursor[D] + long_list[D] + tile sums / counter (pad) + long-segment row slots
+    return 3 * (size_t)d->D * sizeof(uint32_t) + 4096 + (size_t)long_sort_blocks() * d->B * sizeof(int32_t);
 }
 
 extern "C" int mtc_build_csc(const mtc_desc* d, const int32_t* row_ptr, const int32_t* col_idx, void* workspace,
@@ -226,21 +264,29 @@ extern "C" int mtc_build_csc(const mtc_desc* d, const int32_t* row_ptr, const in
     MTC_REQUIRE(row_ptr && col_idx && workspace && col_ptr && csc_row && csc_pos, "mtc_build_csc: null pointer");
     MTC_REQUIRE(workspace_bytes >= mtc_csc_workspace_bytes(d), "mtc_build_csc: workspace too small");
     MTC_REQUIRE(d->B <= 65536, "mtc_build_csc: B > 65536 unsupported");
-    uint32_t* counts = reinterpret_cast<uint32_t*>(workspace);
+    const int n_tiles = (d->D + SCAN_TILE - 1) / SCAN_TILE;
+    MTC_REQUIRE(n_tiles <= 1000, "mtc_build_csc: D too large");
+    // layout: [n_long (1) | tile_sum (<=1000) | pad to 1024 words] counts[D] cursor[D] long_list[D] slots
+    uint32_t* n_long = reinterpret_cast<uint32_t*>(workspace);
+    uint32_t* tile_sum = n_long + 1;
+    uint32_t* counts = n_long + 1024;
     uint32_t* cursor = counts + d->D;
-    int32_t* slots = reinterpret_cast<int32_t*>(cursor + d->D);
+    int32_t* long_list = reinterpret_cast<int32_t*>(cursor + d->D);
+    int32_t* slots = long_list + d->D;
     hipStream_t s = as_stream(stream);
-    if (hipMemsetAsync(counts, 0, (size_t)d->D * sizeof(uint32_t), s) != hipSuccess) {
+    if (hipMemsetAsync(workspace, 0, (1024 + (size_t)d->D) * sizeof(uint32_t), s) != hipSuccess) {
         set_error("mtc_build_csc: memset failed");
         return -2;
     }
     const dim3 rgrid((d->B + 3) / 4), block(256);
     hipLaunchKernelGGL(csc_count_kernel, rgrid, block, 0, s, d->B, row_ptr, col_idx, counts);
-    hipLaunchKernelGGL(csc_scan_kernel, dim3(1), dim3(1024), 0, s, d->D, counts, col_ptr, cursor, cnt);
+    hipLaunchKernelGGL(csc_tile_sum_kernel, dim3(n_tiles), dim3(1024), 0, s, d->D, counts, tile_sum);
+    hipLaunchKernelGGL(csc_scan_kernel, dim3(n_tiles), dim3(1024), 0, s, d->D, n_tiles, counts, tile_sum, col_ptr, cursor, cnt,
+                       long_list, n_long);
     hipLaunchKernelGGL(csc_fill_kernel, rgrid, block, 0, s, d->B, row_ptr, col_idx, cursor, csc_row, csc_pos);
     hipLaunchKernelGGL(csc_sort_kernel, dim3((d->D + 3) / 4), block, 0, s, d->D, col_ptr, csc_row, csc_pos);
-    hipLaunchKernelGGL(csc_sort_long_kernel, dim3(long_sort_blocks()), block, 0, s, d->D, d->B, col_ptr, csc_row, csc_pos,
-                       slots);
+    hipLaunchKernelGGL(csc_sort_long_kernel, dim3(long_sort_blocks()), block, 0, s, d->B, col_ptr, long_list, n_long, csc_row,
+                       csc_pos, slots);
     return check_launch("mtc_build_csc");
 }
 

@@ -12,6 +12,7 @@
 // order until k are selected), and one wavefront per row compacts its selected entries in
 // ascending column order (= prefix-group order).  Everything stays on the device.
 #include "common.hpp"
+#include "rowops.hpp"
 
 namespace mtc {
 
@@ -44,22 +45,24 @@ __global__ __launch_bounds__(256) void select_hist_kernel(const void* __restrict
     const int sh = level_shift(level);
     const uint32_t fm = level_mask(level), pm = level_prefix_mask(level);
     if (!(all_pos && level > 0)) {
-        for (size_t c = (size_t)blockIdx.x * 256 + threadIdx.x; c < n_chunks; c += (size_t)gridDim.x * 256) {
-            uint32_t keys[8];
-            if (DT == MTC_BF16) {
-                const u32x4 r = reinterpret_cast<const u32x4*>(acts)[c];
+        // 4 independent 16-byte loads per lane per iteration (memory-level parallelism)
+        const size_t stride = (size_t)gridDim.x * 256;
+        for (size_t c0 = (size_t)blockIdx.x * 256 + threadIdx.x; c0 < n_chunks; c0 += 4 * stride) {
+            Raw<DT> r[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { keys[2 * i] = r[i] << 16; keys[2 * i + 1] = r[i] & 0xffff0000u; }
-            } else {
-                const u32x4 a = reinterpret_cast<const u32x4*>(acts)[2 * c], b = reinterpret_cast<const u32x4*>(acts)[2 * c + 1];
+            for (int u = 0; u < 4; ++u)
+                if (c0 + u * stride < n_chunks) r[u] = load_raw<DT>(acts, (c0 + u * stride) * 8);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { keys[i] = a[i]; keys[4 + i] = b[i]; }
-            }
+            for (int u = 0; u < 4; ++u) {
+                if (c0 + u * stride >= n_chunks) break;
+                float v[8];
+                unpack(r[u], v);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const uint32_t k = keys[i];
-                // positive, finite-or-inf, not NaN, and (levels > 0) inside the bin chosen so far
-                if (k != 0 && k <= 0x7f800000u && ((k ^ prefix) & pm) == 0) atomicAdd(&lh[(k >> sh) & fm], 1u);
+                for (int i = 0; i < 8; ++i) {
+                    const uint32_t k = __float_as_uint(v[i]);
+                    // positive, finite-or-inf, not NaN, and (levels > 0) inside the bin chosen so far
+                    if (k != 0 && k <= 0x7f800000u && ((k ^ prefix) & pm) == 0) atomicAdd(&lh[(k >> sh) & fm], 1u);
+                }
             }
         }
     }
@@ -132,13 +135,22 @@ __global__ __launch_bounds__(256) void select_count_kernel(const void* __restric
     else { tau = __uint_as_float(st->tau_bits); ties = true; }
     const size_t base = (size_t)row * D;
     uint32_t gt = 0, eq = 0, mn = 0xffffffffu;
-    for (int c = lane; c < (D >> 3); c += 64) {
-        float v[8];
-        load8<DT>(acts, base + (size_t)c * 8, v);
+    const int nch = D >> 3;
+    for (int c0 = lane; c0 < nch; c0 += 256) {
+        Raw<DT> r[4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            if (nz ? (v[i] != 0.f) : (v[i] > tau)) { ++gt; mn = min(mn, __float_as_uint(v[i])); }
-            else if (ties && v[i] == tau) ++eq;
+        for (int u = 0; u < 4; ++u)
+            if (c0 + 64 * u < nch) r[u] = load_raw<DT>(acts, base + (size_t)(c0 + 64 * u) * 8);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (c0 + 64 * u >= nch) break;
+            float v[8];
+            unpack(r[u], v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (nz ? (v[i] != 0.f) : (v[i] > tau)) { ++gt; mn = min(mn, __float_as_uint(v[i])); }
+                else if (ties && v[i] == tau) ++eq;
+            }
         }
     }
     gt = wave_sum_u32(gt); eq = wave_sum_u32(eq);
@@ -230,46 +242,55 @@ __global__ __launch_bounds__(256) void select_fill_kernel(const void* __restrict
     uint32_t out = (uint32_t)row_ptr[row];
     uint32_t ties_seen = 0;                             // wave-uniform running count of == tau in this row
     T* vout = reinterpret_cast<T*>(vals);
-    for (int c0 = 0; c0 < (D >> 3); c0 += 64) {
-        const int c = c0 + lane;
-        float v[8];
-        uint32_t gtm = 0, eqm = 0;
-        if (c < (D >> 3)) {
-            load8<DT>(acts, base + (size_t)c * 8, v);
+    const int nch = D >> 3;
+    for (int cb = 0; cb < nch; cb += 256) {
+        Raw<DT> r[4];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                if (nz ? (v[i] != 0.f) : (v[i] > tau)) gtm |= 1u << i;
-                else if (quota && v[i] == tau) eqm |= 1u << i;
+        for (int u = 0; u < 4; ++u)
+            if (cb + 64 * u + lane < nch) r[u] = load_raw<DT>(acts, base + (size_t)(cb + 64 * u + lane) * 8);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = cb + 64 * u + lane;
+            if (cb + 64 * u >= nch) break;                   // wave-uniform
+            float v[8];
+            uint32_t gtm = 0, eqm = 0;
+            if (c < nch) {
+                unpack(r[u], v);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    if (nz ? (v[i] != 0.f) : (v[i] > tau)) gtm |= 1u << i;
+                    else if (quota && v[i] == tau) eqm |= 1u << i;
+                }
             }
-        }
-        const uint64_t any = __ballot((gtm | eqm) != 0);
-        if (any == 0) continue;                          // wave-uniform
-        uint32_t selm = gtm;
-        if (quota && __ballot(eqm != 0)) {
-            // tie rank = ties in earlier lanes + ties seen in earlier iterations
-            const uint32_t ne = __popc(eqm);
-            uint32_t inc = ne;
+            const uint64_t any = __ballot((gtm | eqm) != 0);
+            if (any == 0) continue;                          // wave-uniform
+            uint32_t selm = gtm;
+            if (quota && __ballot(eqm != 0)) {
+                // tie rank = ties in earlier lanes + ties seen in earlier blocks
+                const uint32_t ne = __popc(eqm);
+                uint32_t inc = ne;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { const uint32_t n = __shfl_up(inc, o, 64); if (lane >= o) inc += n; }
+                uint32_t rank = ties_seen + inc - ne;
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (eqm & (1u << i)) { if (rank < quota) selm |= 1u << i; ++rank; }
+                ties_seen += __shfl(inc, 63, 64);
+            }
+            const uint32_t ns = __popc(selm);
+            uint32_t inc = ns;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) { const uint32_t n = __shfl_up(inc, o, 64); if (lane >= o) inc += n; }
-            uint32_t rank = ties_seen + inc - ne;
+            uint32_t pos = out + inc - ns;
 #pragma unroll
             for (int i = 0; i < 8; ++i)
-                if (eqm & (1u << i)) { if (rank < quota) selm |= 1u << i; ++rank; }
-            ties_seen += __shfl(inc, 63, 64);
+                if (selm & (1u << i)) {
+                    col_idx[pos] = c * 8 + i;
+                    DType<DT>::st(vout + pos, v[i]);
+                    ++pos;
+                }
+            out += __shfl(inc, 63, 64);
         }
-        const uint32_t ns = __popc(selm);
-        uint32_t inc = ns;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t n = __shfl_up(inc, o, 64); if (lane >= o) inc += n; }
-        uint32_t pos = out + inc - ns;
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (selm & (1u << i)) {
-                col_idx[pos] = c * 8 + i;
-                DType<DT>::st(vout + pos, v[i]);
-                ++pos;
-            }
-        out += __shfl(inc, 63, 64);
     }
 }
 

@@ -275,3 +275,20 @@ def test_aux_path_against_oracle(name, gpu_lib):
     if f32:
         for k in ("W_enc", "W_dec", "b_enc", "b_dec"):
             _close(getattr(m, k).grad, s0["grads"][k], 1e-4, 1e-7, f"grad {k} vs reference")
+
+
+def test_dense_features_long_csc_segments(gpu_lib):
+    """Edge: a few features fire on every row (segments > 64 entries): long-segment CSC ordering and the
+    per-feature gradient rows with hundreds of contributions."""
+    cfg = dict(seed=3, prefix_sizes=[64, 128, 256, 512], act_size=64, top_k=8, top_k_aux=8, aux_penalty=1 / 32,
+               n_batches_to_dead=20, l1_coeff=0.0, dtype=torch.float32, device="cpu", input_unit_norm=False)
+    params = R.init_params(cfg)
+    params["b_enc"][[3, 200, 511]] = 5.0
+    g = torch.Generator("cpu").manual_seed(8)
+    xs, xt = torch.randn(320, 64, generator=g), torch.randn(320, 64, generator=g)
+    hp = _hot(cfg)
+    cnt = torch.zeros(512)
+    res = run_forward(hp, cfg, params, cnt, xs, xt)
+    check_against_oracle(cfg, params, cnt, xs, xt, res, hp)
+    cp = res["sel"].col_ptr.cpu()
+    assert int((cp[1:] - cp[:-1]).max()) == 320
