@@ -162,6 +162,114 @@ __global__ __launch_bounds__(256) void select_count_kernel(const void* __restric
     }
 }
 
+// bf16 fast path: after level 0 only 3 key bits remain, so one pass per row can count, for every
+// row, the entries above the level-0 bin and the 8 sub-bin populations inside it; tau, the tie
+// quota and the per-row (> tau, == tau) counts then follow without another pass over acts.
+__global__ __launch_bounds__(256) void select_rowsub_bf16_kernel(const void* __restrict__ acts, int B, int D,
+                                                                 mtc_select_state* __restrict__ st,
+                                                                 uint32_t* __restrict__ row_above,
+                                                                 uint32_t* __restrict__ row_sub /* [B][8] */) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B) return;
+    const bool all_pos = st->all_pos != 0;
+    const uint32_t bin = st->key_prefix >> 19;            // level-0 bin of tau
+    const size_t base = (size_t)row * D;
+    const int nch = D >> 3;
+    uint32_t above = 0, mn = 0xffffffffu;
+    uint32_t sub[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int c0 = lane; c0 < nch; c0 += 512) {
+        Raw<MTC_BF16> r[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (c0 + 64 * u < nch) r[u] = load_raw<MTC_BF16>(acts, base + (size_t)(c0 + 64 * u) * 8);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (c0 + 64 * u >= nch) break;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const uint32_t k = h ? (r[u].v[i] & 0xffff0000u) : (r[u].v[i] << 16);
+                    if (k == 0 || k > 0x7f800000u) continue;
+                    const uint32_t kb = k >> 19;
+                    if (all_pos || kb > bin) { ++above; mn = min(mn, k); }
+                    else if (kb == bin) {
+                        const uint32_t sidx = (k >> 16) & 7u;
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) sub[q] += (sidx == (uint32_t)q) ? 1u : 0u;
+                    }
+                }
+            }
+        }
+    }
+    above = wave_sum_u32(above);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) sub[q] = wave_sum_u32(sub[q]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, o, 64));
+    if (lane == 0) {
+        row_above[row] = above;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) row_sub[(size_t)row * 8 + q] = sub[q];
+        if (mn != 0xffffffffu) atomicMin(&st->min_sel_bits, mn);
+    }
+}
+
+// one workgroup: global sub-bin totals -> tau / quota -> per-row (> tau, == tau)
+__global__ __launch_bounds__(1024) void select_finish_bf16_kernel(int B, mtc_select_state* st,
+                                                                  const uint32_t* __restrict__ row_above,
+                                                                  const uint32_t* __restrict__ row_sub,
+                                                                  uint32_t* __restrict__ row_gt, uint32_t* __restrict__ row_eq) {
+    __shared__ uint32_t sm[16][8];
+    __shared__ uint32_t s_star;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const bool all_pos = st->all_pos != 0;
+    uint32_t tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int r = t; r < B; r += 1024)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) tot[q] += row_sub[(size_t)r * 8 + q];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { tot[q] = wave_sum_u32(tot[q]); if (lane == 0) sm[w][q] = tot[q]; }
+    __syncthreads();
+    if (t == 0) {
+        uint32_t star = 0;
+        if (!all_pos) {
+            const uint32_t k_rem = st->k_rem;
+            uint32_t above = 0;
+            for (int q = 7; q >= 0; --q) {
+                uint32_t h = 0;
+                for (int i = 0; i < 16; ++i) h += sm[i][q];
+                if (above < k_rem && k_rem <= above + h) {
+                    star = (uint32_t)q;
+                    st->n_gt += above;
+                    st->k_rem = k_rem - above;
+                    st->key_prefix |= (uint32_t)q << 16;
+                    st->tau_bits = st->key_prefix;
+                    st->n_tie_take = k_rem - above;
+                    break;
+                }
+                above += h;
+            }
+        }
+        s_star = star;
+    }
+    __syncthreads();
+    const uint32_t star = s_star;
+    for (int r = t; r < B; r += 1024) {
+        uint32_t gt = row_above[r], eq = 0;
+        if (!all_pos) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const uint32_t c = row_sub[(size_t)r * 8 + q];
+                if ((uint32_t)q > star) gt += c;
+                else if ((uint32_t)q == star) eq = c;
+            }
+        }
+        row_gt[r] = gt; row_eq[r] = eq;
+    }
+}
+
 // block-wide exclusive scan helper (1024 threads); returns exclusive prefix of v, total in *total
 __device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t* sm /*[16]*/, uint32_t* total) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -396,7 +504,7 @@ extern "C" int mtc_select_fill(const mtc_desc* d, const void* acts, const mtc_se
 
 extern "C" size_t mtc_select_workspace_bytes(const mtc_desc* d) {
     if (!d) return 0;
-    return 3 * HIST_BINS * sizeof(uint32_t) + 3 * (size_t)((d->B + 63) & ~63) * sizeof(uint32_t);
+    return 3 * HIST_BINS * sizeof(uint32_t) + 12 * (size_t)((d->B + 63) & ~63) * sizeof(uint32_t);
 }
 
 extern "C" int mtc_select_global_topk(const mtc_desc* d, const void* acts, uint32_t k_total, const void* threshold,
@@ -412,6 +520,24 @@ extern "C" int mtc_select_global_topk(const mtc_desc* d, const void* acts, uint3
     uint32_t* tie_take = row_eq + bpad;
     int rc;
     if ((rc = mtc_select_init(st, k_total, stream))) return rc;
+    if (!threshold && d->dtype == MTC_BF16) {
+        // level-0 histogram, then one per-row pass that resolves the remaining 3 key bits
+        uint32_t* row_above = tie_take + bpad;
+        uint32_t* row_sub = row_above + bpad;
+        if (hipMemsetAsync(hist, 0, HIST_BINS * sizeof(uint32_t), as_stream(stream)) != hipSuccess) {
+            set_error("mtc_select_global_topk: memset failed");
+            return -2;
+        }
+        if ((rc = mtc_select_hist(d, acts, 0, st, hist, stream))) return rc;
+        if ((rc = mtc_select_scan(d, 0, hist, st, stream))) return rc;
+        hipLaunchKernelGGL(select_rowsub_bf16_kernel, dim3((d->B + 3) / 4), dim3(256), 0, as_stream(stream), acts, d->B, d->D,
+                           st, row_above, row_sub);
+        hipLaunchKernelGGL(select_finish_bf16_kernel, dim3(1), dim3(1024), 0, as_stream(stream), d->B, st, row_above, row_sub,
+                           row_gt, row_eq);
+        if ((rc = check_launch("mtc_select_global_topk"))) return rc;
+        if ((rc = mtc_select_offsets(d, row_gt, row_eq, nullptr, st, row_ptr, tie_take, stream))) return rc;
+        return mtc_select_fill(d, acts, st, threshold, row_ptr, tie_take, col_idx, vals, stream);
+    }
     if (!threshold) {
         const int levels = mtc_select_levels(d);
         if (hipMemsetAsync(hist, 0, 3 * HIST_BINS * sizeof(uint32_t), as_stream(stream)) != hipSuccess) {
