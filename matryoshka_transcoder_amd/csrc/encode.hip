@@ -12,6 +12,7 @@
 //   read group hit 16 distinct 16-byte slots (conflict free).
 //   Block ids are remapped so that each XCD walks a contiguous range of 8x8 super-tiles
 //   (private 4 MiB L2 per XCD).
+#include <stdlib.h>
 #include "common.hpp"
 
 namespace mtc {
@@ -92,6 +93,15 @@ __device__ __forceinline__ void xcd_tile_coords(int bid, int nblk, int mt, int n
     const int in = lid - g * per_group;
     tm = first_m + in % gsz;
     tn = in / gsz;
+}
+
+// ReLU that never emits -0.0 (the select reads bit patterns), packed to 4 bf16
+__device__ __forceinline__ uint2 relu_pack4(float p0, float p1, float p2, float p3) {
+    p0 = p0 > 0.f ? p0 : 0.f; p1 = p1 > 0.f ? p1 : 0.f; p2 = p2 > 0.f ? p2 : 0.f; p3 = p3 > 0.f ? p3 : 0.f;
+    uint2 o;
+    o.x = (__float_as_uint(p0) >> 16) | (__float_as_uint(p1) & 0xffff0000u);
+    o.y = (__float_as_uint(p2) >> 16) | (__float_as_uint(p3) & 0xffff0000u);
+    return o;
 }
 
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
@@ -189,14 +199,195 @@ __global__ __launch_bounds__(256, 2) void encode_bf16_mfma_kernel(const u16* __r
             const int b = bbase + j * 16;
             if (b >= M) continue;
             const f32x4 v = acc[i][j];
-            const float p0 = fmaxf(round_bf16(round_bf16(v[0]) + b0), 0.f);
-            const float p1 = fmaxf(round_bf16(round_bf16(v[1]) + b1), 0.f);
-            const float p2 = fmaxf(round_bf16(round_bf16(v[2]) + b2), 0.f);
-            const float p3 = fmaxf(round_bf16(round_bf16(v[3]) + b3), 0.f);
-            uint2 o;
-            o.x = (__float_as_uint(p0) >> 16) | (__float_as_uint(p1) & 0xffff0000u);
-            o.y = (__float_as_uint(p2) >> 16) | (__float_as_uint(p3) & 0xffff0000u);
-            *reinterpret_cast<uint2*>(acts + (size_t)b * N + f) = o;
+            *reinterpret_cast<uint2*>(acts + (size_t)b * N + f) =
+                relu_pack4(round_bf16(round_bf16(v[0]) + b0), round_bf16(round_bf16(v[1]) + b1),
+                           round_bf16(round_bf16(v[2]) + b2), round_bf16(round_bf16(v[3]) + b3));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------- K1 bf16 MFMA, 256x256 tile
+// Large problems (>= 2 tiles per CU): 256 (batch) x 256 (features) x 64 tiles double the FLOP per
+// operand byte of the 128^2 kernel (whose 64 FLOP/B needs ~37 TB/s of L2 at MFMA peak).  One
+// workgroup of 8 waves per CU (128 KiB LDS: 2 buffers x {W half 0, W half 1, X half 0, X half 1} of
+// 128 rows x 128 B, same XOR swizzle as above); wave (wr, wc) owns 128 features x 64 batch rows =
+// 8 x 4 accumulator tiles (128 VGPRs).  The two wave groups wr = 0 / 1 share each SIMD pairwise and
+// run HALF A PHASE APART (group 1 passes one extra barrier up front): while one group issues its
+// LDS fragment reads and the LDS-DMA loads of the next K tile, the other runs a cluster of 16
+// MFMAs (one 64x32 quadrant x K = 64) at raised priority; every barrier swaps the roles.
+//   phase 0: read W(m0) [8 x b128] + X(n0) [4]; stage W half 0 of tile kt+1;           MFMA (m0, n0)
+//   phase 1: read X(n1) [4];                    stage W half 1 of tile kt+1;           MFMA (m0, n1)
+//   phase 2: read W(m1) [8];                                                           MFMA (m1, n1)
+//   phase 3: stage both X halves of tile kt+2, then vmcnt(4) (= all of tile kt+1 in);  MFMA (m1, n0)
+// LDS-DMA loads therefore get 4-10 barrier intervals to land and the wait is counted, never a drain.
+// A staged buffer is first read one barrier after every wave's wait, and restaged only after the
+// barrier that follows the lgkmcnt(0) of its last reader.
+constexpr int B2M = 256, B2N = 256;
+constexpr int HALF_BYTES = 128 * 128;          // 16 KiB: 128 rows x 64 bf16
+
+// MFMA intrinsics are pure at the IR level, so LLVM may sink / hoist them across s_barrier; pinning the
+// fragments after the barrier and the accumulators before the next one (empty asm, "+v") keeps each
+// 16-MFMA cluster between its two barriers.
+template <int I0, int J0>
+__device__ __forceinline__ void mfma_quadrant(bf16x8 (&wf)[2][4], bf16x8 (&xf)[2][2], f32x4 (&acc)[8][4]) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(wf[ks][i]));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(xf[ks][j]));
+    }
+#ifndef MTC_ABLATE_NOPRIO
+    __builtin_amdgcn_s_setprio(1);
+#endif
+#ifndef MTC_ABLATE_NOMFMA
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[I0 + i][J0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][i], xf[ks][j], acc[I0 + i][J0 + j], 0, 0, 0);
+#endif
+#ifndef MTC_ABLATE_NOPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(acc[I0 + i][J0 + j]));
+}
+
+#define PHASE_FENCE() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+__global__ __launch_bounds__(512, 1) void encode_bf16_mfma256_kernel(const u16* __restrict__ X, const u16* __restrict__ Wt,
+                                                                     const u16* __restrict__ bias, u16* __restrict__ acts,
+                                                                     int M, int N, int K, int mt, int nt) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int tm, tn;
+    xcd_tile_coords(blockIdx.x, mt * nt, mt, nt, tm, tn);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3;
+    const int row0 = tm * B2M, col0 = tn * B2N;
+
+    // ---- staging: half-tile h (0,1 = W halves; 2,3 = X halves) has 16 pieces of 8 rows; wave wid moves 2 of them
+    const u16* src[4][2];
+#pragma unroll
+    for (int h = 0; h < 4; ++h)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int r = (wid * 2 + q) * 8 + (lane >> 3);                  // row inside the half-tile
+            const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+            if (h < 2) src[h][q] = Wt + (size_t)min(col0 + h * 128 + r, N - 1) * K + chunk * 8;
+            else src[h][q] = X + (size_t)min(row0 + (h - 2) * 128 + r, M - 1) * K + chunk * 8;
+        }
+    auto stage_half = [&](int buf, int h, int kt) {
+        char* base = smem + buf * 4 * HALF_BYTES + h * HALF_BYTES + wid * 2 * 1024;
+        glds16(src[h][0] + kt * BK, base);
+        glds16(src[h][1] + kt * BK, base + 1024);
+    };
+
+    const int fr = lane & 15, fq = lane >> 4;
+    const int swz = (fr >> 1) & 7;
+    int off[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) off[ks] = fr * 128 + (((ks * 4 + fq) ^ swz) << 4);
+    const int w_base = wr * HALF_BYTES;                                          // this wave's W half-tile
+    const int x_base = (2 + (wc >> 1)) * HALF_BYTES + (wc & 1) * 64 * 128;     // its 64 batch rows
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 wf[2][4], xa[2][2], xb[2][2];
+
+    const int ktiles = K / BK;
+    // prologue: tile 0 entirely, plus the X halves of tile 1 (the staging schedule below runs that far ahead)
+#pragma unroll
+    for (int h = 0; h < 4; ++h) stage_half(0, h, 0);
+    if (ktiles > 1) {
+        stage_half(1, 2, 1); stage_half(1, 3, 1);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    PHASE_FENCE();
+    if (wr == 1) PHASE_FENCE();                                                  // stagger the second wave group
+
+    // Staging schedule (buffer = tile parity).  A half-tile may be overwritten once the barrier after the
+    // lgkmcnt(0) of its last reader has passed: X halves are last read in phase 1, W halves in phase 2.
+    //   tile kt, phase 0: W half 0 of tile kt+1      phase 1: W half 1 of tile kt+1
+    //            phase 3: X halves of tile kt+2, then vmcnt(4): everything older (all of tile kt+1) has landed
+    for (int kt = 0; kt < ktiles; ++kt) {
+        const char* cur = smem + (kt & 1) * 4 * HALF_BYTES;
+        const int nb = (kt + 1) & 1;
+#ifdef MTC_ABLATE_NOGLDS
+        const bool more = false, more2 = false;
+#else
+        const bool more = kt + 1 < ktiles, more2 = kt + 2 < ktiles;
+#endif
+        // ---------------- phase 0
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) xa[ks][j] = *reinterpret_cast<const bf16x8*>(cur + x_base + j * 16 * 128 + off[ks]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wf[ks][i] = *reinterpret_cast<const bf16x8*>(cur + w_base + i * 16 * 128 + off[ks]);
+        }
+        if (more) stage_half(nb, 0, kt + 1);
+        PHASE_FENCE();
+        mfma_quadrant<0, 0>(wf, xa, acc);
+        PHASE_FENCE();
+        // ---------------- phase 1
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) xb[ks][j] = *reinterpret_cast<const bf16x8*>(cur + x_base + (2 + j) * 16 * 128 + off[ks]);
+        if (more) stage_half(nb, 1, kt + 1);
+        PHASE_FENCE();
+        mfma_quadrant<0, 2>(wf, xb, acc);
+        PHASE_FENCE();
+        // ---------------- phase 2
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wf[ks][i] = *reinterpret_cast<const bf16x8*>(cur + w_base + (4 + i) * 16 * 128 + off[ks]);
+        PHASE_FENCE();
+        mfma_quadrant<4, 2>(wf, xb, acc);
+        PHASE_FENCE();
+        // ---------------- phase 3
+        if (more2) {
+            stage_half(kt & 1, 2, kt + 2); stage_half(kt & 1, 3, kt + 2);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        PHASE_FENCE();
+        mfma_quadrant<4, 0>(wf, xa, acc);
+        PHASE_FENCE();
+    }
+    if (wr == 0) PHASE_FENCE();                                                  // pair group 1's last barrier
+
+    // ---- epilogue: lane holds features f = fbase + i*16 + r (r = 0..3) of batch row b = bbase + j*16
+    const int fbase = col0 + wr * 128 + fq * 4;
+    const int bbase = row0 + wc * 64 + fr;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int f = fbase + i * 16;
+        if (f >= N) continue;
+        const uint2 bb = *reinterpret_cast<const uint2*>(bias + f);
+        const float b0 = bf16_bits_to_f32(bb.x & 0xffffu), b1 = bf16_bits_to_f32(bb.x >> 16);
+        const float b2 = bf16_bits_to_f32(bb.y & 0xffffu), b3 = bf16_bits_to_f32(bb.y >> 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int b = bbase + j * 16;
+            if (b >= M) continue;
+            const f32x4 v = acc[i][j];
+            *reinterpret_cast<uint2*>(acts + (size_t)b * N + f) =
+                relu_pack4(round_bf16(round_bf16(v[0]) + b0), round_bf16(round_bf16(v[1]) + b1),
+                           round_bf16(round_bf16(v[2]) + b2), round_bf16(round_bf16(v[3]) + b3));
         }
     }
 }
@@ -249,7 +440,7 @@ __global__ __launch_bounds__(256) void encode_generic_kernel(const void* __restr
             const int c = col0 + tx * 4 + j;
             if (c >= N) continue;
             const float pre = D_::rnd(D_::rnd(acc[i][j]) + D_::ld(bp + c));
-            D_::st(out + (size_t)r * N + c, fmaxf(pre, 0.f));
+            D_::st(out + (size_t)r * N + c, pre > 0.f ? pre : 0.f);
         }
     }
 }
@@ -276,7 +467,16 @@ extern "C" int mtc_encode_fwd(const mtc_desc* d, const void* x, const void* W_en
     if (check_desc(d, "mtc_encode_fwd")) return -1;
     MTC_REQUIRE(x && W_encT && b_enc && acts, "mtc_encode_fwd: null pointer");
     const int M = d->B, N = d->D, K = d->A_s;
-    if (d->dtype == MTC_BF16 && (K % BK) == 0) {
+    const char* force = getenv("MTC_ENCODE_TILE");
+    const int big_tiles = ((M + B2M - 1) / B2M) * ((N + B2N - 1) / B2N);
+    if (d->dtype == MTC_BF16 && (K % BK) == 0 && ((big_tiles >= 512 && !(force && force[0] == '1')) || (force && force[0] == '2'))) {
+        const int lds = 2 * 4 * HALF_BYTES;
+        hipFuncSetAttribute(reinterpret_cast<const void*>(encode_bf16_mfma256_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        const int mt = (M + B2M - 1) / B2M, nt = (N + B2N - 1) / B2N;
+        hipLaunchKernelGGL(encode_bf16_mfma256_kernel, dim3(mt * nt), dim3(512), lds, as_stream(stream),
+                           (const u16*)x, (const u16*)W_encT, (const u16*)b_enc, (u16*)acts, M, N, K, mt, nt);
+    } else if (d->dtype == MTC_BF16 && (K % BK) == 0) {
         const int lds = 2 * 2 * TILE_BYTES;
         hipFuncSetAttribute(reinterpret_cast<const void*>(encode_bf16_mfma_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
