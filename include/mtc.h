@@ -85,6 +85,16 @@ int mtc_select_hist(const mtc_desc* d, const void* acts, int level, const mtc_se
                     uint32_t* hist, void* stream);
 int mtc_select_scan(const mtc_desc* d, int level, const uint32_t* hist, mtc_select_state* st,
                     void* stream);
+/* bf16 shortcut for levels >= 1: after level 0 only 3 key bits remain, so ONE pass per row counts
+ * the entries above the level-0 bin (row_above[B]) and the 8 sub-bin populations inside it
+ * (row_sub[B][8]); mtc_select_finish_rows then fixes tau / the tie quota from the sub-bin totals
+ * (global_sub[8]: all-reduced totals when sharded, NULL = sum row_sub locally) and derives the
+ * per-row (> tau, == tau) counts without touching acts again. */
+int mtc_select_rowsub(const mtc_desc* d, const void* acts, mtc_select_state* st, uint32_t* row_above,
+                      uint32_t* row_sub, void* stream);
+int mtc_select_finish_rows(const mtc_desc* d, mtc_select_state* st, const uint32_t* row_above,
+                           const uint32_t* row_sub, const uint32_t* global_sub, uint32_t* row_gt,
+                           uint32_t* row_eq, void* stream);
 /* per-row counts of values > tau and == tau (or, threshold mode, > *threshold: sae.py:189-191;
  * a NaN *threshold selects every non-zero entry: dense -> CSR for decode()) */
 int mtc_select_count(const mtc_desc* d, const void* acts, const mtc_select_state* st,
@@ -125,14 +135,21 @@ int mtc_decode_fwd(const mtc_desc* d, const int32_t* row_ptr, const int32_t* col
                    void* recons, float* d_vals /* NULL, or [nnz]: fused a11 sweep, see
                    mtc_decode_bwd_vals */, float l1_term, void* stream);
 
-/* feature-sharded variant: partial (bias-free) cumulative reconstructions in fp32,
- * partial[G][B][A_t]; after the all-reduce mtc_decode_finish() does the epilogue above. */
+/* feature-sharded variant.  mtc_decode_partial writes this shard's bias-free cumulative sums:
+ *   partial_last [B][A_t] fp32 (last prefix: feeds the loss and the gradient), and
+ *   partial_pre  [(B/rows_per_shard)][G-1][rows_per_shard][A_t] model dtype (earlier prefixes: FVU only),
+ * grouped by the rank that will own the rows so that a reduce-scatter hands each rank one
+ * contiguous block.  mtc_decode_finish then runs the decode epilogue on THIS rank's rows
+ * (d->B = local rows, B_total = global batch for the 2/(B*A_t) factor): partial_pre
+ * [G-1][rows][A_t], x_target / mean / std / x_hat / g / row_stats[G+4][rows] all local. */
 int mtc_decode_partial(const mtc_desc* d, const int32_t* row_ptr, const int32_t* col_idx,
-                       const void* vals, const void* W_dec, float* partial,
+                       const void* vals, const void* W_dec, int32_t rows_per_shard,
+                       float* partial_last, void* partial_pre,
                        float* abs_rows /* [B] sum |a| of the local entries, or NULL */, void* stream);
-int mtc_decode_finish(const mtc_desc* d, const float* partial, const void* b_dec,
-                      const void* x_target, const void* mean, const void* std, void* x_hat,
-                      void* g, float* row_stats, void* recons, void* stream);
+int mtc_decode_finish(const mtc_desc* d, int32_t B_total, const float* partial_last,
+                      const void* partial_pre, const void* b_dec, const void* x_target,
+                      const void* mean, const void* std, void* x_hat, void* g, float* row_stats,
+                      void* recons, void* stream);
 
 /* a8/a10/a14  scalar epilogue: reduces row_stats (and the optional aux partials) to the
  * reference's output scalars without leaving the device.

@@ -41,6 +41,8 @@ PROTOTYPES = {
     "mtc_select_init": (C.c_int, [P, C.c_uint32, P]),
     "mtc_select_hist": (C.c_int, [DP, P, C.c_int, P, P, P]),
     "mtc_select_scan": (C.c_int, [DP, C.c_int, P, P, P]),
+    "mtc_select_rowsub": (C.c_int, [DP, P, P, P, P, P]),
+    "mtc_select_finish_rows": (C.c_int, [DP, P, P, P, P, P, P, P]),
     "mtc_select_count": (C.c_int, [DP, P, P, P, P, P, P]),
     "mtc_select_offsets": (C.c_int, [DP, P, P, P, P, P, P, P]),
     "mtc_select_fill": (C.c_int, [DP, P, P, P, P, P, P, P, P]),
@@ -48,8 +50,8 @@ PROTOTYPES = {
     "mtc_select_global_topk": (C.c_int, [DP, P, C.c_uint32, P, P, C.c_size_t, P, P, P, P, P]),
     "mtc_threshold_ema": (C.c_int, [DP, P, P, C.c_float, P]),
     "mtc_decode_fwd": (C.c_int, [DP, P, P, P, P, P, P, P, P, P, P, P, P, P, C.c_float, P]),
-    "mtc_decode_partial": (C.c_int, [DP, P, P, P, P, P, P, P]),
-    "mtc_decode_finish": (C.c_int, [DP, P, P, P, P, P, P, P, P, P, P]),
+    "mtc_decode_partial": (C.c_int, [DP, P, P, P, P, C.c_int32, P, P, P, P]),
+    "mtc_decode_finish": (C.c_int, [DP, C.c_int32, P, P, P, P, P, P, P, P, P, P, P]),
     "mtc_reduce_scalars": (C.c_int, [DP, P, P, P, P, C.c_int32, C.c_float, C.c_float, P, P]),
     "mtc_decode_bwd_vals": (C.c_int, [DP, P, P, P, P, C.c_float, P, P]),
     "mtc_csc_workspace_bytes": (C.c_size_t, [DP]),

@@ -188,7 +188,8 @@ template <int DT, int NC>
 __global__ __launch_bounds__(256) void decode_partial_kernel(DecodeParams p, const int32_t* __restrict__ row_ptr,
                                                              const int32_t* __restrict__ col_idx,
                                                              const void* __restrict__ vals, const void* __restrict__ W_dec,
-                                                             float* __restrict__ partial, float* __restrict__ abs_rows) {
+                                                             int rps, float* __restrict__ partial_last,
+                                                             void* __restrict__ partial_pre, float* __restrict__ abs_rows) {
     typedef DType<DT> D_;
     typedef typename D_::T T;
     RowCtx<DT, NC> rc;
@@ -202,10 +203,16 @@ __global__ __launch_bounds__(256) void decode_partial_kernel(DecodeParams p, con
     for (int c = 0; c < NC; ++c)
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc[c][k] = 0.f;
+    // rows are grouped by the rank that will finish them (rps rows each) so that a reduce-scatter hands
+    // every rank one contiguous block: pre[(shard*(G-1) + gi)*rps + r], last[row] (already shard-major)
+    const int shard = row / rps, r_in = row - shard * rps;
     auto flush = [&](int gi) {
 #pragma unroll
         for (int c = 0; c < NC; ++c)
-            if (rc.valid(c)) store8<MTC_F32>(partial, ((size_t)gi * p.B + row) * p.A_t + rc.off(c), acc[c]);
+            if (rc.valid(c)) {
+                if (gi == p.G - 1) store8<MTC_F32>(partial_last, (size_t)row * p.A_t + rc.off(c), acc[c]);
+                else store8<DT>(partial_pre, (((size_t)shard * (p.G - 1) + gi) * rps + r_in) * p.A_t + rc.off(c), acc[c]);
+            }
     };
     int gi = 0;
     float abs_sum = 0.f;
@@ -228,9 +235,11 @@ __global__ __launch_bounds__(256) void decode_partial_kernel(DecodeParams p, con
     if (rc.lane == 0 && abs_rows) abs_rows[row] = abs_sum;
 }
 
-// epilogue of the sharded path on the all-reduced partials (one wave per row, no gather)
+// epilogue of the sharded path on the reduced partials of this rank's rows (one wave per row, no gather);
+// p.B = local rows, p.coef carries the GLOBAL batch
 template <int DT>
-__global__ __launch_bounds__(256) void decode_finish_kernel(DecodeParams p, const float* __restrict__ partial,
+__global__ __launch_bounds__(256) void decode_finish_kernel(DecodeParams p, const float* __restrict__ partial_last,
+                                                            const void* __restrict__ partial_pre,
                                                             const void* __restrict__ b_dec, const void* __restrict__ x_target,
                                                             const void* __restrict__ mean_p, const void* __restrict__ std_p,
                                                             void* __restrict__ x_hat, void* __restrict__ g_out,
@@ -254,7 +263,8 @@ __global__ __launch_bounds__(256) void decode_finish_kernel(DecodeParams p, cons
         for (int c = lane; c < nch; c += 64) {
             float a[8], b[8], t[8], r[8], gg[8];
             const size_t off = (size_t)c * 8;
-            load8<MTC_F32>(partial, ((size_t)gi * p.B + row) * p.A_t + off, a);
+            if (last) load8<MTC_F32>(partial_last, (size_t)row * p.A_t + off, a);
+            else load8<DT>(partial_pre, ((size_t)gi * p.B + row) * p.A_t + off, a);
             load8<DT>(b_dec, off, b);
             load8<DT>(x_target, (size_t)row * p.A_t + off, t);
 #pragma unroll
@@ -376,28 +386,35 @@ extern "C" int mtc_decode_bwd_vals(const mtc_desc* d, const int32_t* row_ptr, co
 }
 
 extern "C" int mtc_decode_partial(const mtc_desc* d, const int32_t* row_ptr, const int32_t* col_idx, const void* vals,
-                                  const void* W_dec, float* partial, float* abs_rows, void* stream) {
+                                  const void* W_dec, int32_t rows_per_shard, float* partial_last, void* partial_pre,
+                                  float* abs_rows, void* stream) {
     if (check_desc(d, "mtc_decode_partial")) return -1;
-    MTC_REQUIRE(row_ptr && col_idx && vals && W_dec && partial, "mtc_decode_partial: null pointer");
+    MTC_REQUIRE(row_ptr && col_idx && vals && W_dec && partial_last && (partial_pre || d->G == 1),
+                "mtc_decode_partial: null pointer");
+    MTC_REQUIRE(rows_per_shard > 0 && d->B % rows_per_shard == 0,
+                "mtc_decode_partial: rows_per_shard (%d) must divide B (%d)", rows_per_shard, d->B);
     const DecodeParams p = make_params(d, 0.f);
     DISPATCH_NC(d->dtype, nc_for(d->A_t), decode_partial_kernel, dim3((d->B + 3) / 4), dim3(256), as_stream(stream), p,
-                row_ptr, col_idx, vals, W_dec, partial, abs_rows);
+                row_ptr, col_idx, vals, W_dec, rows_per_shard, partial_last, partial_pre, abs_rows);
     return check_launch("mtc_decode_partial");
 }
 
-extern "C" int mtc_decode_finish(const mtc_desc* d, const float* partial, const void* b_dec, const void* x_target,
-                                 const void* mean, const void* std, void* x_hat, void* g, float* row_stats,
-                                 void* recons, void* stream) {
+extern "C" int mtc_decode_finish(const mtc_desc* d, int32_t B_total, const float* partial_last, const void* partial_pre,
+                                 const void* b_dec, const void* x_target, const void* mean, const void* std, void* x_hat,
+                                 void* g, float* row_stats, void* recons, void* stream) {
     if (check_desc(d, "mtc_decode_finish")) return -1;
-    MTC_REQUIRE(partial && b_dec && x_target && x_hat && row_stats, "mtc_decode_finish: null pointer");
+    MTC_REQUIRE(partial_last && (partial_pre || d->G == 1) && b_dec && x_target && x_hat && row_stats,
+                "mtc_decode_finish: null pointer");
     MTC_REQUIRE(!d->unit_norm || (mean && std), "mtc_decode_finish: unit_norm needs mean/std");
-    const DecodeParams p = make_params(d, 0.f);
+    MTC_REQUIRE(B_total >= d->B, "mtc_decode_finish: B_total (%d) < local rows (%d)", B_total, d->B);
+    DecodeParams p = make_params(d, 0.f);
+    p.coef = (float)(2.0 / ((double)B_total * (double)d->A_t));
     if (d->dtype == MTC_BF16)
         hipLaunchKernelGGL(decode_finish_kernel<MTC_BF16>, dim3((d->B + 3) / 4), dim3(256), 0, as_stream(stream), p,
-                           partial, b_dec, x_target, mean, std, x_hat, g, row_stats, recons);
+                           partial_last, partial_pre, b_dec, x_target, mean, std, x_hat, g, row_stats, recons);
     else
         hipLaunchKernelGGL(decode_finish_kernel<MTC_F32>, dim3((d->B + 3) / 4), dim3(256), 0, as_stream(stream), p,
-                           partial, b_dec, x_target, mean, std, x_hat, g, row_stats, recons);
+                           partial_last, partial_pre, b_dec, x_target, mean, std, x_hat, g, row_stats, recons);
     return check_launch("mtc_decode_finish");
 }
 

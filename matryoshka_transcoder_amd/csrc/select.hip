@@ -220,6 +220,7 @@ __global__ __launch_bounds__(256) void select_rowsub_bf16_kernel(const void* __r
 __global__ __launch_bounds__(1024) void select_finish_bf16_kernel(int B, mtc_select_state* st,
                                                                   const uint32_t* __restrict__ row_above,
                                                                   const uint32_t* __restrict__ row_sub,
+                                                                  const uint32_t* __restrict__ global_sub /* [8] or null */,
                                                                   uint32_t* __restrict__ row_gt, uint32_t* __restrict__ row_eq) {
     __shared__ uint32_t sm[16][8];
     __shared__ uint32_t s_star;
@@ -239,7 +240,8 @@ __global__ __launch_bounds__(1024) void select_finish_bf16_kernel(int B, mtc_sel
             uint32_t above = 0;
             for (int q = 7; q >= 0; --q) {
                 uint32_t h = 0;
-                for (int i = 0; i < 16; ++i) h += sm[i][q];
+                if (global_sub) h = global_sub[q];
+                else for (int i = 0; i < 16; ++i) h += sm[i][q];
                 if (above < k_rem && k_rem <= above + h) {
                     star = (uint32_t)q;
                     st->n_gt += above;
@@ -502,6 +504,26 @@ extern "C" int mtc_select_fill(const mtc_desc* d, const void* acts, const mtc_se
     return check_launch("mtc_select_fill");
 }
 
+extern "C" int mtc_select_rowsub(const mtc_desc* d, const void* acts, mtc_select_state* st, uint32_t* row_above,
+                                 uint32_t* row_sub, void* stream) {
+    if (check_desc(d, "mtc_select_rowsub")) return -1;
+    MTC_REQUIRE(d->dtype == MTC_BF16, "mtc_select_rowsub: bf16 only (fp32 keeps 19 key bits after level 0)");
+    MTC_REQUIRE(acts && st && row_above && row_sub, "mtc_select_rowsub: null pointer");
+    hipLaunchKernelGGL(select_rowsub_bf16_kernel, dim3((d->B + 3) / 4), dim3(256), 0, as_stream(stream), acts, d->B, d->D, st,
+                       row_above, row_sub);
+    return check_launch("mtc_select_rowsub");
+}
+
+extern "C" int mtc_select_finish_rows(const mtc_desc* d, mtc_select_state* st, const uint32_t* row_above,
+                                      const uint32_t* row_sub, const uint32_t* global_sub, uint32_t* row_gt,
+                                      uint32_t* row_eq, void* stream) {
+    if (check_desc(d, "mtc_select_finish_rows")) return -1;
+    MTC_REQUIRE(st && row_above && row_sub && row_gt && row_eq, "mtc_select_finish_rows: null pointer");
+    hipLaunchKernelGGL(select_finish_bf16_kernel, dim3(1), dim3(1024), 0, as_stream(stream), d->B, st, row_above, row_sub,
+                       global_sub, row_gt, row_eq);
+    return check_launch("mtc_select_finish_rows");
+}
+
 extern "C" size_t mtc_select_workspace_bytes(const mtc_desc* d) {
     if (!d) return 0;
     return 3 * HIST_BINS * sizeof(uint32_t) + 12 * (size_t)((d->B + 63) & ~63) * sizeof(uint32_t);
@@ -530,11 +552,8 @@ extern "C" int mtc_select_global_topk(const mtc_desc* d, const void* acts, uint3
         }
         if ((rc = mtc_select_hist(d, acts, 0, st, hist, stream))) return rc;
         if ((rc = mtc_select_scan(d, 0, hist, st, stream))) return rc;
-        hipLaunchKernelGGL(select_rowsub_bf16_kernel, dim3((d->B + 3) / 4), dim3(256), 0, as_stream(stream), acts, d->B, d->D,
-                           st, row_above, row_sub);
-        hipLaunchKernelGGL(select_finish_bf16_kernel, dim3(1), dim3(1024), 0, as_stream(stream), d->B, st, row_above, row_sub,
-                           row_gt, row_eq);
-        if ((rc = check_launch("mtc_select_global_topk"))) return rc;
+        if ((rc = mtc_select_rowsub(d, acts, st, row_above, row_sub, stream))) return rc;
+        if ((rc = mtc_select_finish_rows(d, st, row_above, row_sub, nullptr, row_gt, row_eq, stream))) return rc;
         if ((rc = mtc_select_offsets(d, row_gt, row_eq, nullptr, st, row_ptr, tie_take, stream))) return rc;
         return mtc_select_fill(d, acts, st, threshold, row_ptr, tie_take, col_idx, vals, stream);
     }

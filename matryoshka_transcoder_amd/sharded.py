@@ -11,10 +11,11 @@ S_r; b_dec, the threshold and the batch are replicated.
 Step (RCCL through torch.distributed; every exchange is a real data dependency of the algorithm):
   1. local encoder GEMM on the slice;
   2. global TopK threshold: per radix level, local 4096-bin histogram -> all-reduce(sum) (16 KiB)
-     -> identical scan on every rank; ties at tau are granted in (row, rank, feature) order from an
+     -> identical scan on every rank (bf16: one level + an 8-bin all-reduce); ties at tau are granted in (row, rank, feature) order from an
      all-gather of per-row tie counts ([world, B] ints);
-  3. local sparse decode into bias-free per-prefix partial sums -> all-reduce(sum) of
-     [G, B, A_t] fp32 -> every rank finishes x_hat, losses, FVU and g identically;
+  3. local sparse decode into bias-free per-prefix partial sums -> reduce-scatter over batch rows
+     (last prefix fp32, earlier prefixes -- FVU only -- in the model dtype) -> each rank finishes
+     x_hat / per-prefix SSE / g for B/world rows -> all-gather of x_hat and g (model dtype);
   4. backward and Adam are local to the shard (no gradient all-reduce); db_dec is identical
      everywhere because g is.
 `state_dict()` gathers to the reference's layout; `load_state_dict()` scatters from it.
@@ -95,6 +96,17 @@ class _Comm:
             dist.all_reduce(t, op=op, group=self.group)
         return t
 
+    def reduce_scatter(self, t: torch.Tensor) -> torch.Tensor:
+        """Sum over ranks of t [world * n, ...]; returns this rank's block [n, ...]."""
+        n = t.shape[0] // self.world
+        if self.staged:
+            h = t.float().cpu() if t.is_cuda else t.float()
+            dist.all_reduce(h, group=self.group)
+            return h[self.rank * n:(self.rank + 1) * n].to(device=t.device, dtype=t.dtype)
+        out = torch.empty((n,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        dist.reduce_scatter_tensor(out, t.contiguous(), group=self.group)
+        return out
+
     def all_gather(self, t: torch.Tensor) -> torch.Tensor:
         if self.staged and t.is_cuda:
             h = t.cpu()
@@ -148,14 +160,25 @@ class ShardedMatryoshkaTranscoder(MatryoshkaTranscoder):
         k_total = int(self.config["top_k"]) * B
         st = torch.empty(16, dtype=torch.int32, device=dev)
         check(lib.mtc_select_init(_p(st), k_total, s), "mtc_select_init")
-        for level in range(lib.mtc_select_levels(C.byref(d))):
+        row_gt = torch.empty(B, dtype=torch.int32, device=dev)
+        row_eq = torch.empty(B, dtype=torch.int32, device=dev)
+        bf16 = self.dtype == torch.bfloat16
+        for level in range(1 if bf16 else lib.mtc_select_levels(C.byref(d))):
             hist = torch.zeros(4096, dtype=torch.int32, device=dev)
             check(lib.mtc_select_hist(C.byref(d), _p(acts), level, _p(st), _p(hist), s), "mtc_select_hist")
             self.comm.all_reduce(hist)
             check(lib.mtc_select_scan(C.byref(d), level, _p(hist), _p(st), s), "mtc_select_scan")
-        row_gt = torch.empty(B, dtype=torch.int32, device=dev)
-        row_eq = torch.empty(B, dtype=torch.int32, device=dev)
-        check(lib.mtc_select_count(C.byref(d), _p(acts), _p(st), None, _p(row_gt), _p(row_eq), s), "mtc_select_count")
+        if bf16:
+            # 3 key bits left: one pass per row, then the 8 sub-bin totals are all-reduced (32 bytes)
+            row_above = torch.empty(B, dtype=torch.int32, device=dev)
+            row_sub = torch.empty(B, 8, dtype=torch.int32, device=dev)
+            check(lib.mtc_select_rowsub(C.byref(d), _p(acts), _p(st), _p(row_above), _p(row_sub), s), "mtc_select_rowsub")
+            gsub = row_sub.sum(0, dtype=torch.int32)
+            self.comm.all_reduce(gsub)
+            check(lib.mtc_select_finish_rows(C.byref(d), _p(st), _p(row_above), _p(row_sub), _p(gsub), _p(row_gt),
+                                             _p(row_eq), s), "mtc_select_finish_rows")
+        else:
+            check(lib.mtc_select_count(C.byref(d), _p(acts), _p(st), None, _p(row_gt), _p(row_eq), s), "mtc_select_count")
         before = tie_before(self.comm.all_gather(row_eq), self.comm.rank).contiguous()
         row_ptr = torch.empty(B + 1, dtype=torch.int32, device=dev)
         tie_take = torch.empty(B, dtype=torch.int32, device=dev)
@@ -183,24 +206,40 @@ class ShardedMatryoshkaTranscoder(MatryoshkaTranscoder):
                                 "model yet (single-GPU MatryoshkaTranscoder has it)")
         cfg = self.config
         lib, s, dev = hp.lib, _stream(), x_target.device
-        B, A_t, G = d.B, hp.A_t, d.G
-        partial = torch.empty(G, B, A_t, dtype=torch.float32, device=dev)
+        B, A_t, G, W, rank = d.B, hp.A_t, d.G, self.comm.world, self.comm.rank
+        if B % W:
+            raise _lib.MtcError(f"the batch ({B} rows) must be a multiple of the world size ({W})")
+        rps = B // W
+        # local bias-free partial sums: last prefix fp32, earlier prefixes (FVU only) in the model dtype
+        p_last = torch.empty(B, A_t, dtype=torch.float32, device=dev)
+        p_pre = torch.empty(W, max(G - 1, 1), rps, A_t, dtype=self.dtype, device=dev)
         abs_rows = torch.empty(B, dtype=torch.float32, device=dev)
-        check(lib.mtc_decode_partial(C.byref(d), _p(sel.row_ptr), _p(sel.col_idx), _p(sel.vals), _p(W_dec), _p(partial),
-                                     _p(abs_rows), s), "mtc_decode_partial")
-        self.comm.all_reduce(partial)
+        check(lib.mtc_decode_partial(C.byref(d), _p(sel.row_ptr), _p(sel.col_idx), _p(sel.vals), _p(W_dec), rps,
+                                     _p(p_last), _p(p_pre), _p(abs_rows), s), "mtc_decode_partial")
+        # reduce-scatter by batch rows: every rank finishes 1/W of the rows for all G prefixes
+        my_last = self.comm.reduce_scatter(p_last)                         # [rps, A_t] fp32
+        my_pre = self.comm.reduce_scatter(p_pre)[0] if G > 1 else None      # [G-1, rps, A_t]
         nnz_abs = torch.stack([sel.state[7].to(torch.float32), abs_rows.sum()])
         self.comm.all_reduce(nnz_abs)
-        x_hat = torch.empty(B, A_t, dtype=self.dtype, device=dev)
-        g = torch.empty(B, A_t, dtype=self.dtype, device=dev)
-        row_stats = torch.zeros(G + 4, B, dtype=torch.float32, device=dev)
-        check(lib.mtc_decode_finish(C.byref(d), _p(partial), _p(b_dec), _p(x_target), _p(mean), _p(std), _p(x_hat), _p(g),
-                                    _p(row_stats), None, s), "mtc_decode_finish")
+        dl = _lib.make_desc(rps, hp.A_s, hp.A_t, hp.D, hp.prefix, hp.code, hp.unit_norm)
+        lo, hi = rank * rps, (rank + 1) * rps
+        x_hat_l = torch.empty(rps, A_t, dtype=self.dtype, device=dev)
+        g_l = torch.empty(rps, A_t, dtype=self.dtype, device=dev)
+        stats_l = torch.zeros(G + 4, rps, dtype=torch.float32, device=dev)
+        check(lib.mtc_decode_finish(C.byref(dl), B, _p(my_last), _p(my_pre), _p(b_dec), _p(x_target[lo:hi]),
+                                    _p(mean[lo:hi] if mean is not None else None),
+                                    _p(std[lo:hi] if std is not None else None), _p(x_hat_l), _p(g_l), _p(stats_l), None, s),
+              "mtc_decode_finish")
+        # every rank needs all of g (its features fire on any row) and returns the full reconstruction
+        both = self.comm.all_gather(torch.stack([x_hat_l, g_l]))            # [W, 2, rps, A_t]
+        x_hat = both[:, 0].reshape(B, A_t)
+        g = both[:, 1].reshape(B, A_t).contiguous()
+        row_stats = self.comm.all_gather(stats_l).permute(1, 0, 2).reshape(G + 4, B).contiguous()
         l1_term = float(cfg["l1_coeff"]) / (B * self.total_dict_size)
         d_vals = hp.decode_bwd_vals(d, sel, W_dec, g, l1_term) if need_grad else None
         scalars = hp.reduce_scalars(d, row_stats, sel, self.total_dict_size, float(cfg["l1_coeff"]),
                                     float(cfg["aux_penalty"]), nnz_abs_override=nnz_abs)
-        return x_hat, g, d_vals, row_stats, scalars, None
+        return x_hat.contiguous(), g, d_vals, row_stats, scalars, None
 
     # ------------------------------------------------------------------ checkpoints in the reference layout
     def _gather_features(self, local: torch.Tensor, dim: int) -> torch.Tensor:
