@@ -56,7 +56,7 @@ def batch_pool(B, A, dtype, device, n=8):
     return pool
 
 
-def cpu_baseline(workload, dtype, budget_rows=512, steps=2):
+def cpu_baseline(workload, dtype, budget_rows=512, steps=64):
     """Reference algorithm on the host cores: oracle.DenseStep (same ATen call sequence as the
     reference's step), on a bounded sample = `steps` steps at B=budget_rows of the same shapes."""
     from oracle import ref_cpu as R
@@ -66,10 +66,15 @@ def cpu_baseline(workload, dtype, budget_rows=512, steps=2):
     A = cfg["act_size"]
     model = R.DenseStep(cfg)
     pool = batch_pool(budget_rows, A, dtype, "cpu", n=2)
+    print(f"[bench] cpu_baseline: warm-up step on {cores} host threads ...", file=sys.stderr, flush=True)
+    t0 = time.perf_counter()
     model.step(*pool[0])                      # warm-up
+    warm = time.perf_counter() - t0
+    steps = max(1, min(steps, int(25.0 / max(warm, 1e-3))))          # keep the timed sample near 10-30 s
+    print(f"[bench] cpu_baseline: warm-up {warm:.1f} s, timing {steps} step(s)", file=sys.stderr, flush=True)
     t0 = time.perf_counter()
     for i in range(steps):
-        model.step(*pool[i % 2])
+        model.step(*pool[(i + 1) % 2])
     dt = (time.perf_counter() - t0) / steps
     return {"value": budget_rows / dt, "unit": "tokens/s", "cores": cores, "kind": "port",
             "sample": f"{steps} steps at B={budget_rows} rows of the {workload} shapes (D={cfg['prefix_sizes'][-1]}, "
@@ -98,16 +103,13 @@ def stage_times(tc, opt, pool, reps=5):
         setattr(hp, name, inner)
 
     for n in ("normalize", "encode", "select_topk", "threshold_ema", "build_csc", "decode", "decode_bwd_vals", "reduce_scalars",
-              "backward", "unitnorm_adam", "adam_flat"):
+              "backward", "fused_backward_adam", "colsum", "unitnorm_adam", "adam_flat"):
         wrap(n)
     acc = {}
     for r in range(reps):
         names.clear(); evs.clear()
         xs, xt = pool[r % len(pool)]
-        out = tc(xs, xt)
-        out["loss"].backward()
-        opt.step(project=True)
-        opt.zero_grad()
+        opt.train_step(xs, xt)
         torch.cuda.synchronize()
         for n, (e0, e1) in zip(names, evs):
             acc.setdefault(n, []).append(e0.elapsed_time(e1))
@@ -157,11 +159,8 @@ def main():
 
     def step(i):
         xs, xt = pool[i % len(pool)]
-        out = tc(xs, xt)
-        out["loss"].backward()
-        opt.step(project=True)
-        opt.zero_grad()
-        return out
+        # forward chain + {k-sparse gradient -> unit-norm projection -> Adam} per parameter row (training.py:172-179)
+        return opt.train_step(xs, xt)
 
     def fence():
         if world > 1:
@@ -201,20 +200,23 @@ def main():
         s = 2 if dtype == torch.bfloat16 else 4
         nnz = k * B
         flop_enc = 2.0 * B * A * D
-        # algorithmic bytes per launch (DESIGN.md "Kernels"): SURVEY 8(d) per-unit figures x units per launch
+        # algorithmic work per launch: "hbm" = bytes that must cross HBM at least
+        # once (weights / moments / activations streamed, outputs written); "gather" = bytes the k-sparse row
+        # gathers request on top of that, served by L2 / Infinity Cache (reported, not priced against HBM)
         algo = {
-            "encode": ("mfma", flop_enc),
-            "select_topk": ("hbm", B * D * s + nnz * 8),
-            "decode": ("hbm", 2 * nnz * A * s + nnz * 12 + 3 * B * A * s + B * A * 4),
-            "backward": ("hbm", nnz * (A * 4 + A * s) + 2 * D * A * s + B * A * 4),
-            "unitnorm_adam": ("hbm", D * A * 7 * s),
-            "adam_flat": ("hbm", (D * A + D + A) * 7 * s),
+            "encode": ("mfma", flop_enc, 0),
+            "select_topk": ("hbm", B * D * s + nnz * (4 + s) + B * 4, 0),
+            "decode": ("hbm", D * A * s + nnz * (8 + s) + 3 * B * A * s, 2 * nnz * A * s),
+            "fused_backward_adam": ("hbm", 2 * D * A * 6 * s + 2 * B * A * s + nnz * 12, 2 * nnz * A * s),
+            "backward": ("hbm", 2 * D * A * s + 2 * B * A * s + nnz * 12, 2 * nnz * A * s),
         }
         kernels = {}
         for n, t_ms in st.items():
             entry = {"ms": t_ms}
             if n in algo:
-                kind, q = algo[n]
+                kind, q, gather = algo[n]
+                if gather:
+                    entry["gather_GBps"] = gather / (t_ms * 1e-3) / 1e9
                 if kind == "mfma":
                     peak = MFMA_BF16_PEAK_TF if dtype == torch.bfloat16 else MFMA_F32_PEAK_TF
                     ach = q / (t_ms * 1e-3) / 1e12

@@ -206,6 +206,21 @@ int mtc_unitnorm_adam_rows(const mtc_desc* d, void* W_dec, void* grad, void* exp
                            void* stream);
 int mtc_adam_flat(int32_t dtype, size_t n, void* p, const void* grad, void* exp_avg,
                   void* exp_avg_sq, const mtc_adam_hyper* h_host, void* stream);
+/* a11 + a12 + a13 fused (training.py:172-179 as one pass per parameter row): the gradient row of
+ * feature j is built in registers (as mtc_backward_sparse does), rounded to the parameter dtype
+ * like a materialised .grad, and consumed by [projection +] Adam immediately; dense gradients never
+ * reach HBM.  _dec: W_dec rows with the unit-norm projection; _enc: W_encT rows and b_enc.
+ * b_dec still goes through mtc_colsum + mtc_adam_flat.  Not usable while the aux loss is active
+ * (its contributions must be added to the gradient first: use mtc_backward_sparse then). */
+int mtc_fused_backward_adam_dec(const mtc_desc* d, const int32_t* col_ptr, const int32_t* csc_row,
+                                const int32_t* csc_pos, const void* vals, const void* g,
+                                const float* scale, void* W_dec, void* exp_avg, void* exp_avg_sq,
+                                const mtc_adam_hyper* h_host, void* stream);
+int mtc_fused_backward_adam_enc(const mtc_desc* d, const int32_t* col_ptr, const int32_t* csc_row,
+                                const int32_t* csc_pos, const float* d_vals, const void* x_norm,
+                                const float* scale, void* W_encT, void* exp_avg, void* exp_avg_sq,
+                                void* b_enc, void* b_exp_avg, void* b_exp_avg_sq,
+                                const mtc_adam_hyper* h_host, void* stream);
 /* projection only (the reference method called on its own, sae.py:155-163) */
 int mtc_unitnorm_project(const mtc_desc* d, void* W_dec, void* grad, void* stream);
 

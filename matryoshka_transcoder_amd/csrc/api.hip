@@ -34,6 +34,12 @@ int check_desc(const mtc_desc* d, const char* who) {
     }
     if (d->prefix[d->G - 1] != d->D) { set_error("%s: last prefix (%d) must equal D (%d)", who, prev, d->D); return -1; }
     if ((uint64_t)d->B * (uint64_t)d->D >= (1ull << 40)) { set_error("%s: B*D too large", who); return -1; }
+    // the row gathers address whole matrices through 32-bit buffer offsets (rowops.hpp)
+    const uint64_t a_max = (uint64_t)(d->A_s > d->A_t ? d->A_s : d->A_t), es = d->dtype == MTC_BF16 ? 2 : 4;
+    if ((uint64_t)d->D * a_max * es >= (1ull << 31) || (uint64_t)d->B * a_max * 4ull >= (1ull << 31)) {
+        set_error("%s: a weight or batch matrix of 2 GiB or more is unsupported (D*A*elem_size, B*A*4)", who);
+        return -1;
+    }
     return 0;
 }
 

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void aux_fill_kernel(const void* __restrict__ 
                                                        void* __restrict__ vals) {
     typedef typename DType<DT>::T T;
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (row >= B) return;
     const int n_dead = *n_dead_p;
     const uint32_t tau = row_tau[row], quota = row_quota[row];
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void aux_fwd_kernel(int B, int A_t, int unit_n
     RowCtx<DT, NC> rc;
     rc.lane = threadIdx.x & 63;
     rc.nch = A_t >> 3;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (row >= B) return;
     const int e_begin = row_ptr[row], e_end = row_ptr[row + 1];
     float acc[NC][8];

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void csc_fill_kernel(int B, const int32_t* __r
 __global__ __launch_bounds__(256) void csc_sort_kernel(int D, const int32_t* __restrict__ col_ptr,
                                                        int32_t* __restrict__ csc_row, int32_t* __restrict__ csc_pos) {
     const int lane = threadIdx.x & 63;
-    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int j = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (j >= D) return;
     const int s = col_ptr[j], n = col_ptr[j + 1] - s;
     if (n <= 1) return;
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256, (NC <= 5 ? 4 : 2)) void grad_rows_kernel(
     rc.lane = threadIdx.x & 63;
     rc.nch = A >> 3;
     const int lane = rc.lane;
-    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int j = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (j >= D) return;
     const float scale = scale_p ? *scale_p : 1.f;
     float acc[NC][8];

@@ -29,11 +29,18 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __uint_as_float(b << 16); }
 
-// round-to-nearest-even f32 -> bf16 bit pattern (NaN kept a NaN)
+// round-to-nearest-even f32 -> bf16 through the gfx950 converter (v_cvt_pk_bf16_f32: one instruction
+// per PAIR of values; the hand-rolled add-and-shift costs ~6 VALU ops per value and made the Adam
+// and decode epilogues ALU-bound)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
+    const f32x2 v = {lo, hi};
+    const bf16x2 b = __builtin_convertvector(v, bf16x2);
+    return __builtin_bit_cast(uint32_t, b);
+}
 __device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0u;
-    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+    return (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)f);
 }
 __device__ __forceinline__ float round_bf16(float f) { return bf16_bits_to_f32(f32_to_bf16_bits(f)); }
 
@@ -74,7 +81,7 @@ template <int DT> __device__ __forceinline__ void store8(void* base, size_t elem
 template <> __device__ __forceinline__ void store8<MTC_BF16>(void* base, size_t elem_off, const float (&v)[8]) {
     u32x4 r;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) r[i] = f32_to_bf16_bits(v[2 * i]) | (f32_to_bf16_bits(v[2 * i + 1]) << 16);
+    for (int i = 0; i < 4; ++i) r[i] = pack2_bf16(v[2 * i], v[2 * i + 1]);
     *reinterpret_cast<u32x4*>(reinterpret_cast<u16*>(base) + elem_off) = r;
 }
 template <> __device__ __forceinline__ void store8<MTC_F32>(void* base, size_t elem_off, const float (&v)[8]) {

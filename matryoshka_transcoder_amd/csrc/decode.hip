@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256, (NC <= 5 ? MTC_DECODE_WAVES : 2)) void decode_
     RowCtx<DT, NC> rc;
     rc.lane = threadIdx.x & 63;
     rc.nch = p.A_t >> 3;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (row >= p.B) return;
     const int e_begin = row_ptr[row], e_end = row_ptr[row + 1];
     float mean = 0.f, stdv = 1.f;
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256, (NC <= 5 ? MTC_DECODE_WAVES : 2)) void decode_
     RowCtx<DT, NC> rc;
     rc.lane = threadIdx.x & 63;
     rc.nch = A_t >> 3;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (row >= B) return;
     float gr[NC][8];
 #pragma unroll
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void decode_partial_kernel(DecodeParams p, con
     RowCtx<DT, NC> rc;
     rc.lane = threadIdx.x & 63;
     rc.nch = p.A_t >> 3;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (row >= p.B) return;
     const int e_begin = row_ptr[row], e_end = row_ptr[row + 1];
     float acc[NC][8];
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void decode_finish_kernel(DecodeParams p, cons
     typedef DType<DT> D_;
     typedef typename D_::T T;
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (row >= p.B) return;
     float mean = 0.f, stdv = 1.f;
     if (p.unit_norm) {

@@ -11,18 +11,28 @@
 //   den <- sqrt(v) ; den <- den / sqrt(bc2) ; den <- den + eps   [sqrt, div, add_]
 //   p   <- p - (lr/bc1) * (m / den)                              [addcdiv_]
 #include "common.hpp"
+#include "rowops.hpp"
 #include <math.h>
 
 namespace mtc {
 
 struct AdamK {
-    float w1;          // 1 - beta1
+    float w1;            // 1 - beta1
     float beta2;
-    float w2;          // 1 - beta2
-    float bc2_sqrt;    // sqrt(1 - beta2^step)
+    float w2;            // 1 - beta2
+    float inv_bc2_sqrt;  // 1 / sqrt(1 - beta2^step): tensor / python-scalar is a multiply by the reciprocal on the GPU
     float eps;
-    float neg_step;    // -(lr / (1 - beta1^step))
+    float neg_step;      // -(lr / (1 - beta1^step))
 };
+
+// fp32 parameters: IEEE sqrt and division.  bf16 parameters: every intermediate is rounded to 8
+// mantissa bits straight away, so the 1-ulp v_sqrt_f32 / v_rcp_f32 results round to the same bf16
+// value except when the exact result sits within 2^-16 relative of a rounding boundary; the
+// correctly rounded sequences cost ~25 extra VALU ops per element and made the step ALU-bound.
+template <int DT> __device__ __forceinline__ float sqrt_dt(float x) { return sqrtf(x); }
+template <> __device__ __forceinline__ float sqrt_dt<MTC_BF16>(float x) { return __builtin_amdgcn_sqrtf(x); }
+template <int DT> __device__ __forceinline__ float div_dt(float a, float b) { return a / b; }
+template <> __device__ __forceinline__ float div_dt<MTC_BF16>(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 
 template <int DT>
 __device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v, const AdamK& k) {
@@ -30,10 +40,10 @@ __device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v,
     m = D_::rnd(fmaf(k.w1, g - m, m));
     v = D_::rnd(v * k.beta2);
     v = D_::rnd(fmaf(k.w2 * g, g, v));
-    float den = D_::rnd(sqrtf(v));
-    den = D_::rnd(den / k.bc2_sqrt);
+    float den = D_::rnd(sqrt_dt<DT>(v));
+    den = D_::rnd(den * k.inv_bc2_sqrt);
     den = D_::rnd(den + k.eps);
-    p = D_::rnd(fmaf(k.neg_step, m / den, p));
+    p = D_::rnd(fmaf(k.neg_step, div_dt<DT>(m, den), p));
 }
 
 template <int DT>
@@ -56,7 +66,7 @@ __global__ __launch_bounds__(256) void unitnorm_rows_kernel(int D, int A, void* 
                                                             int write_grad) {
     typedef DType<DT> D_;
     const int lane = threadIdx.x & 63;
-    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int j = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (j >= D) return;
     const int nch = A >> 3;
     float w[NC][8], g[NC][8];
@@ -78,7 +88,7 @@ __global__ __launch_bounds__(256) void unitnorm_rows_kernel(int D, int A, void* 
         if (lane + 64 * c < nch) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                w[c][i] = D_::rnd(w[c][i] / norm);                // W_dec_normed
+                w[c][i] = D_::rnd(div_dt<DT>(w[c][i], norm));       // W_dec_normed
                 dot += D_::rnd(g[c][i] * w[c][i]);                // (grad * W_normed).sum(-1)
             }
         }
@@ -103,6 +113,116 @@ __global__ __launch_bounds__(256) void unitnorm_rows_kernel(int D, int A, void* 
     }
 }
 
+// K4 + K5 fused: one wave per feature builds the gradient row in registers (same gather as
+// grad_rows_kernel), rounds it to the parameter dtype exactly as a materialised .grad would be, and
+// applies [unit-norm projection +] Adam to the parameter row straight away -- the dense gradient is
+// never written to or re-read from HBM (saves 2 * 2 * D * A * s bytes per step).
+//   PROJECT = 1: decoder rows (src = g, coef = vals)        PROJECT = 0: encoder rows (src = x_norm,
+//   coef = d_vals) plus the encoder bias element of the feature.
+#ifndef MTC_FUSED_WAVES
+#define MTC_FUSED_WAVES 3
+#endif
+template <int DT, int COEF_DT, int NC, int PROJECT>
+__global__ __launch_bounds__(256, (DT == MTC_BF16 ? (NC <= 5 ? MTC_FUSED_WAVES : 2) : (NC <= 2 ? 4 : NC <= 5 ? 2 : 1))) void fused_grad_adam_kernel(
+    int D, int A, const int32_t* __restrict__ col_ptr, const int32_t* __restrict__ csc_row,
+    const int32_t* __restrict__ csc_pos, const void* __restrict__ coef, const void* __restrict__ src,
+    const float* __restrict__ scale_p, void* __restrict__ W, void* __restrict__ m, void* __restrict__ v,
+    void* __restrict__ bias, void* __restrict__ m_b, void* __restrict__ v_b, AdamK k) {
+    typedef DType<DT> D_;
+    typedef typename D_::T T;
+    RowCtx<DT, NC> rc;
+    rc.lane = threadIdx.x & 63;
+    rc.nch = A >> 3;
+    const int lane = rc.lane;
+    const int j = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (j >= D) return;
+    const float scale = scale_p ? *scale_p : 1.f;
+    float acc[NC][8];
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[c][q] = 0.f;
+    float csum = 0.f;
+    const int s0 = col_ptr[j], e_end = col_ptr[j + 1];
+    for (int e0 = s0; e0 < e_end; e0 += 64) {
+        const int nb = min(64, e_end - e0);
+        int my_row = 0; float my_c = 0.f;
+        if (lane < nb) {
+            my_row = csc_row[e0 + lane];
+            my_c = DType<COEF_DT>::ld(reinterpret_cast<const typename DType<COEF_DT>::T*>(coef) + csc_pos[e0 + lane]);
+        }
+        csum += my_c;
+        accumulate_run<DT, NC>(rc, src, A, my_row, my_c, 0, nb, acc);
+    }
+    // the .grad a dense backward would hold: rounded to the parameter dtype and kept in storage
+    // form (bf16: 4 registers per chunk instead of 8), which frees the registers for the parameter
+    // and moment rows -- all of them are requested before any is consumed
+    Raw<DT> gr[NC], pw[NC], pm[NC], pv[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+        if (rc.valid(c)) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc[c][q] *= scale;
+            gr[c] = pack_raw<DT>(acc[c]);
+        }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+        if (rc.valid(c)) {
+            const size_t off = (size_t)j * A + rc.off(c);
+            pw[c] = load_raw<DT>(W, off);
+            pm[c] = load_raw<DT>(m, off);
+            pv[c] = load_raw<DT>(v, off);
+        }
+    float norm = 1.f, dot = 0.f;
+    if (PROJECT) {
+        float ss = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            if (rc.valid(c)) {
+                float w[8];
+                unpack(pw[c], w);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) ss = fmaf(w[q], w[q], ss);
+            }
+        norm = D_::rnd(sqrtf(wave_sum(ss)));
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            if (rc.valid(c)) {
+                float w[8], g[8];
+                unpack(pw[c], w); unpack(gr[c], g);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) dot += D_::rnd(g[q] * D_::rnd(div_dt<DT>(w[q], norm)));
+            }
+        dot = D_::rnd(wave_sum(dot));
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+        if (rc.valid(c)) {
+            const size_t off = (size_t)j * A + rc.off(c);
+            float w[8], g[8], mm[8], vv[8];
+            unpack(pw[c], w); unpack(gr[c], g); unpack(pm[c], mm); unpack(pv[c], vv);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (PROJECT) {
+                    w[q] = D_::rnd(div_dt<DT>(w[q], norm));
+                    g[q] = D_::rnd(g[q] - D_::rnd(dot * w[q]));
+                }
+                adam_elem<DT>(w[q], g[q], mm[q], vv[q], k);
+            }
+            store8<DT>(W, off, w); store8<DT>(m, off, mm); store8<DT>(v, off, vv);
+        }
+    if (bias) {
+        csum = wave_sum(csum);
+        if (lane == 0) {
+            T* bp = reinterpret_cast<T*>(bias) + j; T* mp = reinterpret_cast<T*>(m_b) + j; T* vp = reinterpret_cast<T*>(v_b) + j;
+            float b = D_::ld(bp), mb = D_::ld(mp), vb = D_::ld(vp);
+            adam_elem<DT>(b, D_::rnd(scale * csum), mb, vb, k);
+            D_::st(bp, b); D_::st(mp, mb); D_::st(vp, vb);
+        }
+    }
+}
+
 static AdamK make_adam(const mtc_adam_hyper* h) {
     AdamK k;
     const double bc1 = 1.0 - pow(h->beta1, (double)h->step);
@@ -110,13 +230,11 @@ static AdamK make_adam(const mtc_adam_hyper* h) {
     k.w1 = (float)(1.0 - h->beta1);
     k.beta2 = (float)h->beta2;
     k.w2 = (float)(1.0 - h->beta2);
-    k.bc2_sqrt = (float)sqrt(bc2);
+    k.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
     k.eps = (float)h->eps;
     k.neg_step = (float)(-(h->lr / bc1));
     return k;
 }
-
-static int nc_for(int A) { return ((A >> 3) + 63) / 64; }
 
 }  // namespace mtc
 
@@ -174,4 +292,53 @@ extern "C" int mtc_adam_flat(int32_t dtype, size_t n, void* p, const void* grad,
     else
         hipLaunchKernelGGL(adam_flat_kernel<MTC_F32>, dim3(grid), dim3(256), 0, as_stream(stream), n_chunks, p, grad, m, v, k);
     return check_launch("mtc_adam_flat");
+}
+
+#define LAUNCH_FUSED(DTV, COEF, PROJ)                                                                                        \
+    do {                                                                                                                     \
+        const int nc_ = nc_for(A);                                                                                           \
+        const dim3 grid((d->D + 3) / 4), block(256);                                                                         \
+        if (nc_ <= 1) hipLaunchKernelGGL((fused_grad_adam_kernel<DTV, COEF, 1, PROJ>), grid, block, 0, s, d->D, A, col_ptr, csc_row, csc_pos, coef, src, scale, W, m, v, bias, m_b, v_b, k); \
+        else if (nc_ <= 2) hipLaunchKernelGGL((fused_grad_adam_kernel<DTV, COEF, 2, PROJ>), grid, block, 0, s, d->D, A, col_ptr, csc_row, csc_pos, coef, src, scale, W, m, v, bias, m_b, v_b, k); \
+        else if (nc_ <= 3) hipLaunchKernelGGL((fused_grad_adam_kernel<DTV, COEF, 3, PROJ>), grid, block, 0, s, d->D, A, col_ptr, csc_row, csc_pos, coef, src, scale, W, m, v, bias, m_b, v_b, k); \
+        else if (nc_ <= 5) hipLaunchKernelGGL((fused_grad_adam_kernel<DTV, COEF, 5, PROJ>), grid, block, 0, s, d->D, A, col_ptr, csc_row, csc_pos, coef, src, scale, W, m, v, bias, m_b, v_b, k); \
+        else if (nc_ <= 7) hipLaunchKernelGGL((fused_grad_adam_kernel<DTV, COEF, 7, PROJ>), grid, block, 0, s, d->D, A, col_ptr, csc_row, csc_pos, coef, src, scale, W, m, v, bias, m_b, v_b, k); \
+        else if (nc_ <= 9) hipLaunchKernelGGL((fused_grad_adam_kernel<DTV, COEF, 9, PROJ>), grid, block, 0, s, d->D, A, col_ptr, csc_row, csc_pos, coef, src, scale, W, m, v, bias, m_b, v_b, k); \
+        else hipLaunchKernelGGL((fused_grad_adam_kernel<DTV, COEF, 16, PROJ>), grid, block, 0, s, d->D, A, col_ptr, csc_row, csc_pos, coef, src, scale, W, m, v, bias, m_b, v_b, k); \
+    } while (0)
+
+extern "C" int mtc_fused_backward_adam_dec(const mtc_desc* d, const int32_t* col_ptr, const int32_t* csc_row,
+                                           const int32_t* csc_pos, const void* vals, const void* g, const float* scale,
+                                           void* W_dec, void* exp_avg, void* exp_avg_sq, const mtc_adam_hyper* h_host,
+                                           void* stream) {
+    if (check_desc(d, "mtc_fused_backward_adam_dec")) return -1;
+    MTC_REQUIRE(col_ptr && csc_row && csc_pos && vals && g && W_dec && exp_avg && exp_avg_sq && h_host,
+                "mtc_fused_backward_adam_dec: null pointer");
+    MTC_REQUIRE(h_host->step >= 1, "mtc_fused_backward_adam_dec: step is 1-based");
+    const AdamK k = make_adam(h_host);
+    hipStream_t s = as_stream(stream);
+    const int A = d->A_t;
+    const void* coef = vals; const void* src = g;
+    void* W = W_dec; void* m = exp_avg; void* v = exp_avg_sq; void* bias = nullptr; void* m_b = nullptr; void* v_b = nullptr;
+    if (d->dtype == MTC_BF16) LAUNCH_FUSED(MTC_BF16, MTC_BF16, 1);
+    else LAUNCH_FUSED(MTC_F32, MTC_F32, 1);
+    return check_launch("mtc_fused_backward_adam_dec");
+}
+
+extern "C" int mtc_fused_backward_adam_enc(const mtc_desc* d, const int32_t* col_ptr, const int32_t* csc_row,
+                                           const int32_t* csc_pos, const float* d_vals, const void* x_norm, const float* scale,
+                                           void* W_encT, void* exp_avg, void* exp_avg_sq, void* b_enc, void* b_exp_avg,
+                                           void* b_exp_avg_sq, const mtc_adam_hyper* h_host, void* stream) {
+    if (check_desc(d, "mtc_fused_backward_adam_enc")) return -1;
+    MTC_REQUIRE(col_ptr && csc_row && csc_pos && d_vals && x_norm && W_encT && exp_avg && exp_avg_sq && b_enc && b_exp_avg &&
+                b_exp_avg_sq && h_host, "mtc_fused_backward_adam_enc: null pointer");
+    MTC_REQUIRE(h_host->step >= 1, "mtc_fused_backward_adam_enc: step is 1-based");
+    const AdamK k = make_adam(h_host);
+    hipStream_t s = as_stream(stream);
+    const int A = d->A_s;
+    const void* coef = d_vals; const void* src = x_norm;
+    void* W = W_encT; void* m = exp_avg; void* v = exp_avg_sq; void* bias = b_enc; void* m_b = b_exp_avg; void* v_b = b_exp_avg_sq;
+    if (d->dtype == MTC_BF16) LAUNCH_FUSED(MTC_BF16, MTC_F32, 0);
+    else LAUNCH_FUSED(MTC_F32, MTC_F32, 0);
+    return check_launch("mtc_fused_backward_adam_enc");
 }

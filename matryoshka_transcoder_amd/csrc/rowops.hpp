@@ -40,6 +40,29 @@ __device__ __forceinline__ void unpack(const Raw<MTC_F32>& r, float (&w)[8]) {
     for (int i = 0; i < 4; ++i) { w[i] = r.a[i]; w[4 + i] = r.b[i]; }
 }
 
+// inverse of unpack: 8 floats -> the storage form (bf16: rounded to nearest even, 4 registers)
+template <int DT> __device__ __forceinline__ Raw<DT> pack_raw(const float (&w)[8]);
+template <> __device__ __forceinline__ Raw<MTC_BF16> pack_raw<MTC_BF16>(const float (&w)[8]) {
+    Raw<MTC_BF16> r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.v[i] = pack2_bf16(w[2 * i], w[2 * i + 1]);
+    return r;
+}
+template <> __device__ __forceinline__ Raw<MTC_F32> pack_raw<MTC_F32>(const float (&w)[8]) {
+    Raw<MTC_F32> r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { r.a[i] = w[i]; r.b[i] = w[4 + i]; }
+    return r;
+}
+template <int DT> __device__ __forceinline__ void store_raw(void* base, size_t elem_off, const Raw<DT>& r);
+template <> __device__ __forceinline__ void store_raw<MTC_BF16>(void* base, size_t elem_off, const Raw<MTC_BF16>& r) {
+    *reinterpret_cast<u32x4*>(reinterpret_cast<u16*>(base) + elem_off) = r.v;
+}
+template <> __device__ __forceinline__ void store_raw<MTC_F32>(void* base, size_t elem_off, const Raw<MTC_F32>& r) {
+    f32x4* p = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + elem_off);
+    p[0] = r.a; p[1] = r.b;
+}
+
 // rows kept in flight per lane: about 8-10 16-byte loads, bounded so that acc (8 NC) + raw rows
 // (4 U NC) stay near 128 VGPRs (4 waves per SIMD)
 #ifndef MTC_GATHER_U5
@@ -47,48 +70,80 @@ __device__ __forceinline__ void unpack(const Raw<MTC_F32>& r, float (&w)[8]) {
 #endif
 __host__ __device__ constexpr int gather_u(int nc) { return nc <= 1 ? 8 : nc <= 2 ? 4 : nc <= 5 ? MTC_GATHER_U5 : 1; }
 
-// acc += a * W[j] for `n` entries starting at index i0 of the lane-resident batch (cols/vals);
-// U rows are requested before any is consumed (U * NC 16-byte loads in flight per lane).
-template <int DT, int NC, int U>
-__device__ __forceinline__ void accumulate_run_u(const RowCtx<DT, NC>& rc, const void* __restrict__ W, int A,
-                                                 int my_col, float my_val, int i0, int n, float (&acc)[NC][8]) {
-    int i = i0;
-    const int end = i0 + n;
-    for (; i + U <= end; i += U) {
-        Raw<DT> r[U][NC];
-        float a[U];
+// Gather loads go through buffer instructions: address = descriptor base + SGPR row offset + a
+// per-lane 32-bit VGPR chunk offset that is fixed for the whole kernel, so a load costs no address
+// arithmetic and no 64-bit address registers.  Lanes of a chunk beyond the row carry an offset
+// past the descriptor's range: the hardware returns zeros without touching memory, which keeps every
+// load unconditional (straight-line code, exact vmcnt bookkeeping).  Matrices must be < 2 GiB
+// (checked on the host: MTC_GATHER_MAX_BYTES).
+#define MTC_GATHER_MAX_BYTES 0x7fffffffull
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
+template <int DT, int NC>
+__device__ __forceinline__ void chunk_byte_offsets(const RowCtx<DT, NC>& rc, uint32_t (&co)[NC]) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int j = __builtin_amdgcn_readlane(my_col, i + u);
-            a[u] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_val), i + u));
-            const size_t rowoff = (size_t)j * A;
+    for (int c = 0; c < NC; ++c)
+        co[c] = rc.valid(c) ? (uint32_t)(rc.lane + 64 * c) * (8u * (uint32_t)sizeof(typename DType<DT>::T)) : 0x80000000u;
+}
+template <int DT> __device__ __forceinline__ Raw<DT> load_raw_at(rsrc_t rs, uint32_t row_off, uint32_t byte_off);
+template <> __device__ __forceinline__ Raw<MTC_BF16> load_raw_at<MTC_BF16>(rsrc_t rs, uint32_t row_off, uint32_t byte_off) {
+    Raw<MTC_BF16> r;
+    r.v = __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, row_off, 0);
+    return r;
+}
+template <> __device__ __forceinline__ Raw<MTC_F32> load_raw_at<MTC_F32>(rsrc_t rs, uint32_t row_off, uint32_t byte_off) {
+    Raw<MTC_F32> r;
+    r.a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, row_off, 0));
+    r.b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off + 16u, row_off, 0));
+    return r;
+}
+
+// acc += a * W[j] for `n` entries starting at index i0 of the lane-resident batch (cols/vals).
+// Rotating pipeline of P rows: inside the main loop row i+P is requested as soon as row i has been
+// consumed, unconditionally, so P * NC 16-byte loads per lane stay in flight and the compiler's
+// vmcnt bookkeeping stays exact across the back edge (conditional refills made it drain the queue at
+// every stage).
+template <int DT, int NC>
+__device__ __forceinline__ void fma_row(const Raw<DT> (&r)[NC], float a, float (&acc)[NC][8]) {
 #pragma unroll
-            for (int c = 0; c < NC; ++c)
-                if (rc.valid(c)) r[u][c] = load_raw<DT>(W, rowoff + rc.off(c));
-        }
+    for (int c = 0; c < NC; ++c) {
+        float w[8];
+        unpack(r[c], w);
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int c = 0; c < NC; ++c)
-                if (rc.valid(c)) {
-                    float w[8];
-                    unpack(r[u][c], w);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) acc[c][k] = fmaf(a[u], w[k], acc[c][k]);
-                }
+        for (int k = 0; k < 8; ++k) acc[c][k] = fmaf(a, w[k], acc[c][k]);
     }
-    for (; i < end; ++i) {
-        const int j = __builtin_amdgcn_readlane(my_col, i);
-        const float a = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_val), i));
-        const size_t rowoff = (size_t)j * A;
+}
+template <int DT, int NC>
+__device__ __forceinline__ void load_row(rsrc_t rs, uint32_t row_bytes, int j, const uint32_t (&co)[NC], Raw<DT> (&r)[NC]) {
+    const uint32_t row_off = (uint32_t)j * row_bytes;
 #pragma unroll
-        for (int c = 0; c < NC; ++c)
-            if (rc.valid(c)) {
-                float w[8];
-                unpack(load_raw<DT>(W, rowoff + rc.off(c)), w);
+    for (int c = 0; c < NC; ++c) r[c] = load_raw_at<DT>(rs, row_off, co[c]);
+}
+template <int DT, int NC, int P>
+__device__ __forceinline__ void accumulate_run_u(const RowCtx<DT, NC>& rc, const void* __restrict__ W, int A,
+                                                 int my_col, float my_val, int i0_, int n_, float (&acc)[NC][8]) {
+    const int i0 = __builtin_amdgcn_readfirstlane(i0_), n = __builtin_amdgcn_readfirstlane(n_);
+    if (n <= 0) return;
+    const uint32_t row_bytes = (uint32_t)A * (uint32_t)sizeof(typename DType<DT>::T);
+    const int end = i0 + n, last = end - 1;
+    uint32_t co[NC];
+    chunk_byte_offsets(rc, co);
+    const rsrc_t Wb = make_rsrc(W);
+    Raw<DT> r[P][NC];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) acc[c][k] = fmaf(a, w[k], acc[c][k]);
-            }
+    for (int u = 0; u < P; ++u)      // a run shorter than P re-requests its last row (cache hit, coefficient 0 below)
+        load_row<DT, NC>(Wb, row_bytes, __builtin_amdgcn_readlane(my_col, min(i0 + u, last)), co, r[u]);
+    for (int i = i0; i < end; i += P) {
+#pragma unroll
+        for (int u = 0; u < P; ++u) {
+            const int cur = i + u;
+            const float a = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_val), min(cur, last)));
+            fma_row<DT, NC>(r[u], cur < end ? a : 0.f, acc);
+            // the refills past the end of the run re-request its last row (cache hits, never consumed)
+            load_row<DT, NC>(Wb, row_bytes, __builtin_amdgcn_readlane(my_col, min(cur + P, last)), co, r[u]);
+        }
     }
 }
 template <int DT, int NC>
@@ -99,11 +154,21 @@ __device__ __forceinline__ void accumulate_run(const RowCtx<DT, NC>& rc, const v
 
 // d_vals_out[i] = g . W[j_i] + l1_term for the `n` (<= 64) entries whose columns sit in my_col.
 // Four rows at a time; the four per-lane partials are folded with 7 cross-lane exchanges
-// (halve the value set while halving the lane set) instead of 4 x 6.
+// (halve the value set while halving the lane set) instead of 4 x 6.  g of chunks beyond the row is
+// treated as zero.
 template <int DT, int NC>
 __device__ __forceinline__ void dot_run(const RowCtx<DT, NC>& rc, const void* __restrict__ W, int A, int my_col,
-                                        int n, const float (&g)[NC][8], float l1_term, float* __restrict__ d_vals_out) {
+                                        int n, const float (&g_in)[NC][8], float l1_term, float* __restrict__ d_vals_out) {
+    const uint32_t row_bytes = (uint32_t)A * (uint32_t)sizeof(typename DType<DT>::T);
     const int lane = rc.lane;
+    uint32_t co[NC];
+    chunk_byte_offsets(rc, co);
+    const rsrc_t Wb = make_rsrc(W);
+    float g[NC][8];
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) g[c][k] = rc.valid(c) ? g_in[c][k] : 0.f;
     int i = 0;
     constexpr int UD = gather_u(NC) >= 4 ? 4 : gather_u(NC);
     for (; i + 4 <= n; i += 4) {
@@ -113,22 +178,17 @@ __device__ __forceinline__ void dot_run(const RowCtx<DT, NC>& rc, const void* __
             Raw<DT> r[UD][NC];
 #pragma unroll
             for (int u = 0; u < UD; ++u) {
-                const int j = __builtin_amdgcn_readlane(my_col, i + h + u);
-                const size_t rowoff = (size_t)j * A;
-#pragma unroll
-                for (int c = 0; c < NC; ++c)
-                    if (rc.valid(c)) r[u][c] = load_raw<DT>(W, rowoff + rc.off(c));
+                load_row<DT, NC>(Wb, row_bytes, __builtin_amdgcn_readlane(my_col, i + h + u), co, r[u]);
             }
 #pragma unroll
             for (int u = 0; u < UD; ++u)
 #pragma unroll
-                for (int c = 0; c < NC; ++c)
-                    if (rc.valid(c)) {
-                        float w[8];
-                        unpack(r[u][c], w);
+                for (int c = 0; c < NC; ++c) {
+                    float w[8];
+                    unpack(r[u][c], w);
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) p[h + u] = fmaf(g[c][k], w[k], p[h + u]);
-                    }
+                    for (int k = 0; k < 8; ++k) p[h + u] = fmaf(g[c][k], w[k], p[h + u]);
+                }
         }
         // lanes < 32 keep entries {0,1}, lanes >= 32 keep {2,3}
         const bool hi = lane >= 32;
@@ -144,17 +204,16 @@ __device__ __forceinline__ void dot_run(const RowCtx<DT, NC>& rc, const void* __
         if ((lane & 15) == 0) d_vals_out[i + 2 * (lane >> 5) + ((lane >> 4) & 1)] = v + l1_term;
     }
     for (; i < n; ++i) {
-        const int j = __builtin_amdgcn_readlane(my_col, i);
-        const size_t rowoff = (size_t)j * A;
+        Raw<DT> r1[NC];
+        load_row<DT, NC>(Wb, row_bytes, __builtin_amdgcn_readlane(my_col, i), co, r1);
         float p = 0.f;
 #pragma unroll
-        for (int c = 0; c < NC; ++c)
-            if (rc.valid(c)) {
-                float w[8];
-                unpack(load_raw<DT>(W, rowoff + rc.off(c)), w);
+        for (int c = 0; c < NC; ++c) {
+            float w[8];
+            unpack(r1[c], w);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) p = fmaf(g[c][k], w[k], p);
-            }
+            for (int k = 0; k < 8; ++k) p = fmaf(g[c][k], w[k], p);
+        }
         p = wave_sum(p);
         if (lane == 0) d_vals_out[i] = p + l1_term;
     }

@@ -275,6 +275,37 @@ class HotPath:
         check(self.lib.mtc_adam_flat(self.code, p.numel(), _p(p), _p(grad), _p(m), _p(v), C.byref(hyper), _stream()),
               "mtc_adam_flat")
 
+    def fused_backward_adam(self, d, sel: Selection, g, d_vals, x_norm, scale, W_dec, st_dec, W_encT, st_enc, b_enc,
+                            st_benc, h_dec: AdamHyper, h_enc: AdamHyper, h_benc: AdamHyper):
+        """a11 + a12 + a13 in two launches; st_* = (exp_avg, exp_avg_sq) in the storage layout of the parameter."""
+        if scale is not None:
+            scale = scale.reshape(1).to(torch.float32).contiguous()
+        for t, n, shp in ((W_dec, "W_dec", (self.D, self.A_t)), (st_dec[0], "exp_avg(W_dec)", (self.D, self.A_t)),
+                          (st_dec[1], "exp_avg_sq(W_dec)", (self.D, self.A_t)), (W_encT, "W_encT", (self.D, self.A_s)),
+                          (st_enc[0], "exp_avg(W_enc)", (self.D, self.A_s)), (st_enc[1], "exp_avg_sq(W_enc)", (self.D, self.A_s)),
+                          (b_enc, "b_enc", (self.D,)), (st_benc[0], "exp_avg(b_enc)", (self.D,)),
+                          (st_benc[1], "exp_avg_sq(b_enc)", (self.D,))):
+            _need(t, n, self.dtype, shp)
+        s = _stream()
+        check(self.lib.mtc_fused_backward_adam_dec(C.byref(d), _p(sel.col_ptr), _p(sel.csc_row), _p(sel.csc_pos), _p(sel.vals),
+                                                   _p(g), _p(scale), _p(W_dec), _p(st_dec[0]), _p(st_dec[1]), C.byref(h_dec), s),
+              "mtc_fused_backward_adam_dec")
+        if h_enc.step != h_benc.step or h_enc.lr != h_benc.lr:
+            raise _lib.MtcError("W_enc and b_enc must share one Adam step count / lr for the fused update")
+        check(self.lib.mtc_fused_backward_adam_enc(C.byref(d), _p(sel.col_ptr), _p(sel.csc_row), _p(sel.csc_pos), _p(d_vals),
+                                                   _p(x_norm), _p(scale), _p(W_encT), _p(st_enc[0]), _p(st_enc[1]), _p(b_enc),
+                                                   _p(st_benc[0]), _p(st_benc[1]), C.byref(h_enc), s),
+              "mtc_fused_backward_adam_enc")
+
+    def colsum(self, d, g, scale=None):
+        db_dec = torch.empty(self.A_t, dtype=self.dtype, device=g.device)
+        ws_bytes = self.lib.mtc_colsum_workspace_bytes(C.byref(d))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=g.device)
+        if scale is not None:
+            scale = scale.reshape(1).to(torch.float32).contiguous()
+        check(self.lib.mtc_colsum(C.byref(d), _p(g), _p(scale), _p(ws), ws_bytes, _p(db_dec), 0, _stream()), "mtc_colsum")
+        return db_dec
+
     # ------------------------------------------------------------------ a15
     def densify(self, d, sel: Selection, max_col: int):
         dense = torch.empty(d.B, self.D, dtype=self.dtype, device=sel.row_ptr.device)

@@ -58,6 +58,53 @@ class FusedAdam(torch.optim.Optimizer):
         self.transcoder = transcoder
         super().__init__(list(transcoder.parameters()), dict(lr=lr, betas=betas, eps=eps))
 
+    def _state(self, p):
+        st = self.state[p]
+        if not st:
+            st["step"] = 0
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        return st
+
+    @torch.no_grad()
+    def train_step(self, x_source, x_target):
+        """One whole training step (training.py:92,172-179) without materialising gradients: forward chain,
+        then per parameter row {k-sparse gradient -> unit-norm projection -> Adam} in one kernel.  Returns the
+        reference's output dict (no autograd graph).  While the auxiliary loss is active the step falls back
+        to dense gradients + `step(project=True)`, because aux contributions must be summed into them first."""
+        tc = self.transcoder
+        if not tc.training:
+            raise _lib.MtcError("train_step() needs the transcoder in training mode")
+        res = tc._run_forward(x_source, x_target, tc.W_enc, tc.b_enc, tc.W_dec, tc.b_dec, True)
+        tc._last_res = res
+        out = tc._output_dict(res, x_target)
+        hp = tc.hot_path()
+        if res.aux is not None:
+            dW_dec, dW_encT, db_enc, db_dec = tc._run_backward(res, None)
+            tc.W_dec.grad, tc.W_enc.grad, tc.b_enc.grad, tc.b_dec.grad = dW_dec, dW_encT.t(), db_enc, db_dec
+            self.step(project=True)
+            self.zero_grad()
+            return out
+        group = self.param_groups[0]
+        b1, b2 = group["betas"]
+        hy = {}
+        for name in ("W_dec", "W_enc", "b_enc", "b_dec"):
+            st = self._state(getattr(tc, name))
+            st["step"] += 1
+            hy[name] = adam_hyper(group["lr"], b1, b2, group["eps"], st["step"])
+        sd, se, sb, sbd = (self.state[getattr(tc, n)] for n in ("W_dec", "W_enc", "b_enc", "b_dec"))
+        W_encT = tc._w_encT(tc.W_enc)
+        m_e, v_e = se["exp_avg"].t(), se["exp_avg_sq"].t()
+        if not m_e.is_contiguous():
+            se["exp_avg"], se["exp_avg_sq"] = m_e.contiguous().t(), v_e.contiguous().t()
+            m_e, v_e = se["exp_avg"].t(), se["exp_avg_sq"].t()
+        hp.fused_backward_adam(res.desc, res.sel, res.g, res.d_vals, res.x_norm, None, tc.W_dec.data,
+                               (sd["exp_avg"], sd["exp_avg_sq"]), W_encT.data, (m_e, v_e), tc.b_enc.data,
+                               (sb["exp_avg"], sb["exp_avg_sq"]), hy["W_dec"], hy["W_enc"], hy["b_enc"])
+        db_dec = hp.colsum(res.desc, res.g)
+        hp.adam_flat(tc.b_dec.data, db_dec, sbd["exp_avg"], sbd["exp_avg_sq"], hy["b_dec"])
+        return out
+
     @torch.no_grad()
     def step(self, closure=None, project: bool = False):
         if closure is not None:
@@ -69,11 +116,7 @@ class FusedAdam(torch.optim.Optimizer):
             for p in group["params"]:
                 if p.grad is None:
                     continue
-                st = self.state[p]
-                if not st:
-                    st["step"] = 0
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st = self._state(p)
                 st["step"] += 1
                 h = adam_hyper(group["lr"], b1, b2, group["eps"], st["step"])
                 if p is tc.W_dec and project:
@@ -119,19 +162,26 @@ def train_transcoder(transcoder, activation_store, model, cfg):
     with open(log_path, "a", encoding="utf-8") as log:
         for i in range(num_batches):
             source_batch, target_batch = activation_store.next_batch()
-            out = transcoder(source_batch, target_batch)
-            if i % cfg.get("perf_log_freq", 1000) == 0:
-                log_transcoder_performance(log, i, model, activation_store, transcoder)
-            if i % cfg.get("checkpoint_freq", 10000) == 0:
-                results.save_checkpoint(exp_dir, transcoder, cfg, i, metrics_of(out), is_final=False)
+            perf_now = i % cfg.get("perf_log_freq", 1000) == 0
+            ckpt_now = i % cfg.get("checkpoint_freq", 10000) == 0
+            if perf_now or ckpt_now:
+                # the reference logs performance / checkpoints between the forward and the update
+                # (training.py:92-171): keep that order with the autograd path on those iterations
+                out = transcoder(source_batch, target_batch)
+                if perf_now:
+                    log_transcoder_performance(log, i, model, activation_store, transcoder)
+                if ckpt_now:
+                    results.save_checkpoint(exp_dir, transcoder, cfg, i, metrics_of(out), is_final=False)
+                out["loss"].backward()
+                optimizer.step(project=True)      # unit-norm projection fused into the W_dec update
+                optimizer.zero_grad()
+            else:
+                out = optimizer.train_step(source_batch, target_batch)     # same numbers, no materialised gradients
             if i % log_freq == 0:
                 rec = metrics_of(out)
                 rec.update(step=i, dead_features_count=int((transcoder.num_batches_not_active >= n_dead_at).sum()),
                            learning_rate=optimizer.param_groups[0]["lr"], elapsed_s=time.time() - t0)
                 log.write(json.dumps(rec) + "\n")
-            out["loss"].backward(retain_graph=True)
-            optimizer.step(project=True)          # unit-norm projection fused into the W_dec update
-            optimizer.zero_grad()
             if scheduler is not None:
                 scheduler.step()
     final_cfg = dict(cfg)

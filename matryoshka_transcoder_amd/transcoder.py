@@ -275,12 +275,17 @@ class MatryoshkaTranscoder(nn.Module):
     def forward(self, x_source, x_target):
         """sae.py:195-269.  Returns the reference's dict; `loss` carries the autograd graph."""
         loss, x_hat, s = _StepFn.apply(self, x_source, x_target, self.W_enc, self.b_enc, self.W_dec, self.b_dec)
-        dt = self.dtype
+        return self._output_dict(self._last_res, x_target, loss=loss)
+
+    def _output_dict(self, res, x_target, loss=None):
+        """The reference's 11 keys with its dtypes (sae.py:257-269), from the device-resident scalars."""
+        s, dt = res.scalars, self.dtype
+        if loss is None:
+            loss = s[5].clone() if res.aux is not None else s[5].to(dt)
         # aux inactive: a 0-dim zero in the target dtype; active: fp32 (sae.py:342-347)
-        aux_loss = s[4] if self._last_res.aux is not None else \
-            torch.zeros((), dtype=x_target.dtype, device=x_target.device)
+        aux_loss = s[4] if res.aux is not None else torch.zeros((), dtype=x_target.dtype, device=x_target.device)
         return {
-            "transcoder_out": x_hat,
+            "transcoder_out": res.x_hat,
             "loss": loss,
             "l2_loss": s[0].to(dt),
             "l1_loss": s[1].to(dt),

@@ -193,3 +193,33 @@ def test_full_size_properties_gemma2_2b(gpu_lib):
     norms = m.W_dec.detach().float().norm(dim=-1)
     assert float((norms - 1).abs().max()) < 2e-2                     # rows stay ~unit norm (post-Adam drift only)
     assert losses[-1] < losses[0]
+
+
+@pytest.mark.parametrize("name", ["fp32_plain", "bf16_unit", "fp32_cross", "fp32_aux", "bf16_aux"])
+def test_fused_train_step_equals_autograd_path(name, gpu_lib):
+    """FusedAdam.train_step (gradient rows consumed in registers) must give bit-identical weights, moments and
+    outputs to forward -> backward -> step(project=True) on dense gradients."""
+    from matryoshka_transcoder_amd.training import FusedAdam
+    fx, cfg = load_golden(name)
+    ma, cfg_d = _model(fx, cfg)
+    mb, _ = _model(fx, cfg)
+    for m in (ma, mb):
+        m.num_batches_not_active = fx["cnt0"].clone().to(DEV)
+    oa = FusedAdam(ma, lr=cfg["lr"], betas=(cfg["beta1"], cfg["beta2"]))
+    ob = FusedAdam(mb, lr=cfg["lr"], betas=(cfg["beta1"], cfg["beta2"]))
+    for s in fx["steps"]:
+        xs, xt = s["x_source"].to(DEV), s["x_target"].to(DEV)
+        out_a = ma(xs, xt)
+        out_a["loss"].backward()
+        oa.step(project=True)
+        oa.zero_grad()
+        out_b = ob.train_step(xs, xt)
+        for k in out_a:
+            assert out_b[k].dtype == out_a[k].dtype
+            assert torch.equal(out_b[k].detach(), out_a[k].detach()), k
+        for (n, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+            assert torch.equal(pa, pb), n
+            assert torch.equal(oa.state[pa]["exp_avg"], ob.state[pb]["exp_avg"]), n
+            assert torch.equal(oa.state[pa]["exp_avg_sq"], ob.state[pb]["exp_avg_sq"]), n
+        assert torch.equal(ma.threshold, mb.threshold)
+        assert torch.equal(ma.num_batches_not_active, mb.num_batches_not_active)

@@ -3,6 +3,7 @@
 events over several repetitions, interleaved, in one process.  Used for A/B work on single kernels."""
 import argparse
 import os
+import re
 import sys
 
 import torch
@@ -51,6 +52,8 @@ def main():
     m, v = torch.zeros_like(W_dec), torch.zeros_like(W_dec)
     grads = hp.backward(d, sel, g, d_vals, xs, None)
     h = adam_hyper(3e-4, 0.9, 0.99, 1e-8, 1)
+    m2, v2 = torch.zeros_like(W_encT), torch.zeros_like(W_encT)
+    mb, vb = torch.zeros_like(b_enc), torch.zeros_like(b_enc)
     big = torch.empty(512 * 1024 * 1024, dtype=torch.uint8, device=dev)
 
     def flush():
@@ -65,15 +68,15 @@ def main():
         "decode_G4_fused": lambda: hp.decode(d, sel, W_dec, b_dec, xt, None, None, want_g=True, want_dvals=True),
         "decode_bwd_vals": lambda: hp.decode_bwd_vals(d, sel, W_dec, g, 0.0),
         "backward": lambda: hp.backward(d, sel, g, d_vals, xs, None),
+        "fused_backward_adam": lambda: hp.fused_backward_adam(
+            d, sel, g, d_vals, xs, None, W_dec, (m, v), W_encT, (m2, v2), b_enc, (mb, vb), h, h, h),
         "unitnorm_adam": lambda: hp.unitnorm_adam(W_dec, grads[0], m, v, h, write_grad=False),
         "adam_flat": lambda: hp.adam_flat(W_dec, grads[0], m, v, h),
     }
     for name, fn in tests.items():
-        if args.only and args.only not in name:
+        if args.only and not re.search(args.only, name):
             continue
         med, mn = timeit(fn)
-        def cold():
-            flush(); 
         # cold-cache variant: flush before each repetition (timed region excludes the flush)
         ts = []
         for _ in range(5):
