@@ -206,8 +206,8 @@ def main():
         algo = {
             "encode": ("mfma", flop_enc, 0),
             "select_topk": ("hbm", B * D * s + nnz * (4 + s) + B * 4, 0),
-            "decode": ("hbm", D * A * s + nnz * (8 + s) + 3 * B * A * s, 2 * nnz * A * s),
-            "fused_backward_adam": ("hbm", 2 * D * A * 6 * s + 2 * B * A * s + nnz * 12, 2 * nnz * A * s),
+            "decode": ("hbm", D * A * s + nnz * (4 + s) + 3 * B * A * s, nnz * A * s),      # one sweep: d_vals is deferred
+            "fused_backward_adam": ("hbm", 2 * D * A * 6 * s + 2 * B * A * s + nnz * 20, 2 * nnz * A * s),
             "backward": ("hbm", 2 * D * A * s + 2 * B * A * s + nnz * 12, 2 * nnz * A * s),
         }
         kernels = {}

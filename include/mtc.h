@@ -211,11 +211,16 @@ int mtc_adam_flat(int32_t dtype, size_t n, void* p, const void* grad, void* exp_
  * like a materialised .grad, and consumed by [projection +] Adam immediately; dense gradients never
  * reach HBM.  _dec: W_dec rows with the unit-norm projection; _enc: W_encT rows and b_enc.
  * b_dec still goes through mtc_colsum + mtc_adam_flat.  Not usable while the aux loss is active
- * (its contributions must be added to the gradient first: use mtc_backward_sparse then). */
+ * (its contributions must be added to the gradient first: use mtc_backward_sparse then).
+ * _dec with d_vals_out != NULL also writes d a_bj = g_b . W_dec[j] + l1_term (pre-update W_dec) for
+ * every selected entry at its CSR position -- the same values as mtc_decode_bwd_vals, from the one
+ * gather of g the decoder gradient needs anyway; mtc_decode_fwd is then called with d_vals = NULL.
+ * Call _dec before _enc (which consumes d_vals). */
 int mtc_fused_backward_adam_dec(const mtc_desc* d, const int32_t* col_ptr, const int32_t* csc_row,
                                 const int32_t* csc_pos, const void* vals, const void* g,
                                 const float* scale, void* W_dec, void* exp_avg, void* exp_avg_sq,
-                                const mtc_adam_hyper* h_host, void* stream);
+                                const mtc_adam_hyper* h_host, float* d_vals_out, float l1_term,
+                                void* stream);
 int mtc_fused_backward_adam_enc(const mtc_desc* d, const int32_t* col_ptr, const int32_t* csc_row,
                                 const int32_t* csc_pos, const float* d_vals, const void* x_norm,
                                 const float* scale, void* W_encT, void* exp_avg, void* exp_avg_sq,

@@ -61,7 +61,7 @@ PROTOTYPES = {
     "mtc_colsum": (C.c_int, [DP, P, P, P, C.c_size_t, P, C.c_int, P]),
     "mtc_unitnorm_adam_rows": (C.c_int, [DP, P, P, P, P, HP, C.c_int, P]),
     "mtc_adam_flat": (C.c_int, [C.c_int32, C.c_size_t, P, P, P, P, HP, P]),
-    "mtc_fused_backward_adam_dec": (C.c_int, [DP, P, P, P, P, P, P, P, P, P, HP, P]),
+    "mtc_fused_backward_adam_dec": (C.c_int, [DP, P, P, P, P, P, P, P, P, P, HP, P, C.c_float, P]),
     "mtc_fused_backward_adam_enc": (C.c_int, [DP, P, P, P, P, P, P, P, P, P, P, P, P, HP, P]),
     "mtc_unitnorm_project": (C.c_int, [DP, P, P, P]),
     "mtc_aux_dead_list": (C.c_int, [DP, P, C.c_float, P, P, P]),

@@ -196,10 +196,13 @@ __global__ __launch_bounds__(256) void aux_fwd_kernel(int B, int A_t, int unit_n
     sse = wave_sum(sse);
     if (rc.lane == 0) aux_rows[row] = sse;
     if (d_aux_vals) {
+        Raw<DT> gp[NC];                       // g_aux as stored (model dtype), zero beyond the row
+#pragma unroll
+        for (int c = 0; c < NC; ++c) gp[c] = rc.valid(c) ? pack_raw<DT>(acc[c]) : zero_raw<DT>();
         for (int e0 = e_begin; e0 < e_end; e0 += 64) {
             const int nb = min(64, e_end - e0);
             const int my_col = rc.lane < nb ? col_idx[e0 + rc.lane] : 0;
-            dot_run<DT, NC>(rc, W_dec, A_t, my_col, nb, acc, 0.f, d_aux_vals + e0);
+            dot_run<DT, NC>(rc, W_dec, A_t, my_col, nb, gp, 0.f, d_aux_vals + e0);
         }
     }
 }

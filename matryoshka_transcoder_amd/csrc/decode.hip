@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256, (NC <= 5 ? MTC_DECODE_WAVES : 2)) void decode_
                 sx += t[k];
                 sxx = fmaf(t[k], t[k], sxx);
                 gg[k] = gscale * dlt;
-                acc[c][k] = gg[k];                    // acc now holds g for the second sweep
+                acc[c][k] = D_::rnd(gg[k]);           // acc now holds g (as stored, in the model dtype) for the second sweep
             }
             store8<DT>(x_hat, (size_t)row * p.A_t + rc.off(c), r);
             if (recons) store8<DT>(reinterpret_cast<T*>(recons) + ((size_t)(p.G - 1) * p.B + row) * p.A_t, rc.off(c), r);
@@ -148,10 +148,13 @@ __global__ __launch_bounds__(256, (NC <= 5 ? MTC_DECODE_WAVES : 2)) void decode_
     }
     // ---- second sweep: d a_bj = g_b . W_dec[j] (+ l1 term)
     if (d_vals) {
+        Raw<DT> gp[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) gp[c] = rc.valid(c) ? pack_raw<DT>(acc[c]) : zero_raw<DT>();
         for (int e0 = e_begin; e0 < e_end; e0 += 64) {
             const int nb = min(64, e_end - e0);
             const int my_col = rc.lane < nb ? col_idx[e0 + rc.lane] : 0;
-            dot_run<DT, NC>(rc, W_dec, p.A_t, my_col, nb, acc, p.l1_term, d_vals + e0);
+            dot_run<DT, NC>(rc, W_dec, p.A_t, my_col, nb, gp, p.l1_term, d_vals + e0);
         }
     }
 }
@@ -167,14 +170,9 @@ __global__ __launch_bounds__(256, (NC <= 5 ? MTC_DECODE_WAVES : 2)) void decode_
     rc.nch = A_t >> 3;
     const int row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (row >= B) return;
-    float gr[NC][8];
+    Raw<DT> gr[NC];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        if (rc.valid(c)) load8<DT>(g, (size_t)row * A_t + rc.off(c), gr[c]);
-        else
-#pragma unroll
-            for (int k = 0; k < 8; ++k) gr[c][k] = 0.f;
-    }
+    for (int c = 0; c < NC; ++c) gr[c] = rc.valid(c) ? load_raw<DT>(g, (size_t)row * A_t + rc.off(c)) : zero_raw<DT>();
     const int e_begin = row_ptr[row], e_end = row_ptr[row + 1];
     for (int e0 = e_begin; e0 < e_end; e0 += 64) {
         const int nb = min(64, e_end - e0);

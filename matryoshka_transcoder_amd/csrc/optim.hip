@@ -122,12 +122,15 @@ __global__ __launch_bounds__(256) void unitnorm_rows_kernel(int D, int A, void* 
 #ifndef MTC_FUSED_WAVES
 #define MTC_FUSED_WAVES 3
 #endif
-template <int DT, int COEF_DT, int NC, int PROJECT>
+//   WITH_DOT = 1 (decoder rows only): the same gather of g also produces d a_bj = g_b . W_dec[j] + l1_term
+//   for the feature's entries (d_vals_out[csc_pos]), which replaces the decode kernel's second sweep.
+template <int DT, int COEF_DT, int NC, int PROJECT, int WITH_DOT>
 __global__ __launch_bounds__(256, (DT == MTC_BF16 ? (NC <= 5 ? MTC_FUSED_WAVES : 2) : (NC <= 2 ? 4 : NC <= 5 ? 2 : 1))) void fused_grad_adam_kernel(
     int D, int A, const int32_t* __restrict__ col_ptr, const int32_t* __restrict__ csc_row,
     const int32_t* __restrict__ csc_pos, const void* __restrict__ coef, const void* __restrict__ src,
     const float* __restrict__ scale_p, void* __restrict__ W, void* __restrict__ m, void* __restrict__ v,
-    void* __restrict__ bias, void* __restrict__ m_b, void* __restrict__ v_b, AdamK k) {
+    void* __restrict__ bias, void* __restrict__ m_b, void* __restrict__ v_b, AdamK k, float* __restrict__ d_vals_out,
+    float l1_term) {
     typedef DType<DT> D_;
     typedef typename D_::T T;
     RowCtx<DT, NC> rc;
@@ -143,21 +146,28 @@ __global__ __launch_bounds__(256, (DT == MTC_BF16 ? (NC <= 5 ? MTC_FUSED_WAVES :
 #pragma unroll
         for (int q = 0; q < 8; ++q) acc[c][q] = 0.f;
     float csum = 0.f;
+    Raw<DT> gr[NC], pw[NC], pm[NC], pv[NC];
+    if constexpr (WITH_DOT != 0) {                     // the (pre-update) parameter row takes part in the gather loop
+        uint32_t co[NC];
+        chunk_byte_offsets(rc, co);          // chunks beyond the row read as zeros
+        load_row<DT, NC>(make_rsrc(W), (uint32_t)A * (uint32_t)sizeof(T), j, co, pw);
+    }
     const int s0 = col_ptr[j], e_end = col_ptr[j + 1];
     for (int e0 = s0; e0 < e_end; e0 += 64) {
         const int nb = min(64, e_end - e0);
-        int my_row = 0; float my_c = 0.f;
+        int my_row = 0, my_pos = 0; float my_c = 0.f;
         if (lane < nb) {
             my_row = csc_row[e0 + lane];
-            my_c = DType<COEF_DT>::ld(reinterpret_cast<const typename DType<COEF_DT>::T*>(coef) + csc_pos[e0 + lane]);
+            my_pos = csc_pos[e0 + lane];
+            my_c = DType<COEF_DT>::ld(reinterpret_cast<const typename DType<COEF_DT>::T*>(coef) + my_pos);
         }
         csum += my_c;
-        accumulate_run<DT, NC>(rc, src, A, my_row, my_c, 0, nb, acc);
+        if constexpr (WITH_DOT != 0) accumulate_dot_run<DT, NC>(rc, src, A, my_row, my_c, my_pos, nb, pw, l1_term, d_vals_out, acc);
+        else accumulate_run<DT, NC>(rc, src, A, my_row, my_c, 0, nb, acc);
     }
     // the .grad a dense backward would hold: rounded to the parameter dtype and kept in storage
     // form (bf16: 4 registers per chunk instead of 8), which frees the registers for the parameter
     // and moment rows -- all of them are requested before any is consumed
-    Raw<DT> gr[NC], pw[NC], pm[NC], pv[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c)
         if (rc.valid(c)) {
@@ -170,7 +180,7 @@ __global__ __launch_bounds__(256, (DT == MTC_BF16 ? (NC <= 5 ? MTC_FUSED_WAVES :
     for (int c = 0; c < NC; ++c)
         if (rc.valid(c)) {
             const size_t off = (size_t)j * A + rc.off(c);
-            pw[c] = load_raw<DT>(W, off);
+            if (!WITH_DOT) pw[c] = load_raw<DT>(W, off);
             pm[c] = load_raw<DT>(m, off);
             pv[c] = load_raw<DT>(v, off);
         }
@@ -294,23 +304,23 @@ extern "C" int mtc_adam_flat(int32_t dtype, size_t n, void* p, const void* grad,
     return check_launch("mtc_adam_flat");
 }
 
-#define LAUNCH_FUSED(DTV, COEF, PROJ)                                                                                        \
+#define LAUNCH_FUSED(DTV, COEF, PROJ, DOT)                                                                                        \
     do {                                                                                                                     \
         const int nc_ = nc_for(A);                                                                                           \
         const dim3 grid((d->D + 3) / 4), block(256);                                                                         \
-        if (nc_ <= 1) hipLaunchKernelGGL((fused_grad_adam_kernel<DTV, COEF, 1, PROJ>), grid, block, 0, s, d->D, A, col_ptr, csc_row, csc_pos, coef, src, scale, W, m, v, bias, m_b, v_b, k); \
-        else if (nc_ <= 2) hipLaunchKernelGGL((fused_grad_adam_kernel<DTV, COEF, 2, PROJ>), grid, block, 0, s, d->D, A, col_ptr, csc_row, csc_pos, coef, src, scale, W, m, v, bias, m_b, v_b, k); \
-        else if (nc_ <= 3) hipLaunchKernelGGL((fused_grad_adam_kernel<DTV, COEF, 3, PROJ>), grid, block, 0, s, d->D, A, col_ptr, csc_row, csc_pos, coef, src, scale, W, m, v, bias, m_b, v_b, k); \
-        else if (nc_ <= 5) hipLaunchKernelGGL((fused_grad_adam_kernel<DTV, COEF, 5, PROJ>), grid, block, 0, s, d->D, A, col_ptr, csc_row, csc_pos, coef, src, scale, W, m, v, bias, m_b, v_b, k); \
-        else if (nc_ <= 7) hipLaunchKernelGGL((fused_grad_adam_kernel<DTV, COEF, 7, PROJ>), grid, block, 0, s, d->D, A, col_ptr, csc_row, csc_pos, coef, src, scale, W, m, v, bias, m_b, v_b, k); \
-        else if (nc_ <= 9) hipLaunchKernelGGL((fused_grad_adam_kernel<DTV, COEF, 9, PROJ>), grid, block, 0, s, d->D, A, col_ptr, csc_row, csc_pos, coef, src, scale, W, m, v, bias, m_b, v_b, k); \
-        else hipLaunchKernelGGL((fused_grad_adam_kernel<DTV, COEF, 16, PROJ>), grid, block, 0, s, d->D, A, col_ptr, csc_row, csc_pos, coef, src, scale, W, m, v, bias, m_b, v_b, k); \
+        if (nc_ <= 1) hipLaunchKernelGGL((fused_grad_adam_kernel<DTV, COEF, 1, PROJ, DOT>), grid, block, 0, s, d->D, A, col_ptr, csc_row, csc_pos, coef, src, scale, W, m, v, bias, m_b, v_b, k, dv_out, l1_term); \
+        else if (nc_ <= 2) hipLaunchKernelGGL((fused_grad_adam_kernel<DTV, COEF, 2, PROJ, DOT>), grid, block, 0, s, d->D, A, col_ptr, csc_row, csc_pos, coef, src, scale, W, m, v, bias, m_b, v_b, k, dv_out, l1_term); \
+        else if (nc_ <= 3) hipLaunchKernelGGL((fused_grad_adam_kernel<DTV, COEF, 3, PROJ, DOT>), grid, block, 0, s, d->D, A, col_ptr, csc_row, csc_pos, coef, src, scale, W, m, v, bias, m_b, v_b, k, dv_out, l1_term); \
+        else if (nc_ <= 5) hipLaunchKernelGGL((fused_grad_adam_kernel<DTV, COEF, 5, PROJ, DOT>), grid, block, 0, s, d->D, A, col_ptr, csc_row, csc_pos, coef, src, scale, W, m, v, bias, m_b, v_b, k, dv_out, l1_term); \
+        else if (nc_ <= 7) hipLaunchKernelGGL((fused_grad_adam_kernel<DTV, COEF, 7, PROJ, DOT>), grid, block, 0, s, d->D, A, col_ptr, csc_row, csc_pos, coef, src, scale, W, m, v, bias, m_b, v_b, k, dv_out, l1_term); \
+        else if (nc_ <= 9) hipLaunchKernelGGL((fused_grad_adam_kernel<DTV, COEF, 9, PROJ, DOT>), grid, block, 0, s, d->D, A, col_ptr, csc_row, csc_pos, coef, src, scale, W, m, v, bias, m_b, v_b, k, dv_out, l1_term); \
+        else hipLaunchKernelGGL((fused_grad_adam_kernel<DTV, COEF, 16, PROJ, DOT>), grid, block, 0, s, d->D, A, col_ptr, csc_row, csc_pos, coef, src, scale, W, m, v, bias, m_b, v_b, k, dv_out, l1_term); \
     } while (0)
 
 extern "C" int mtc_fused_backward_adam_dec(const mtc_desc* d, const int32_t* col_ptr, const int32_t* csc_row,
                                            const int32_t* csc_pos, const void* vals, const void* g, const float* scale,
                                            void* W_dec, void* exp_avg, void* exp_avg_sq, const mtc_adam_hyper* h_host,
-                                           void* stream) {
+                                           float* d_vals_out, float l1_term, void* stream) {
     if (check_desc(d, "mtc_fused_backward_adam_dec")) return -1;
     MTC_REQUIRE(col_ptr && csc_row && csc_pos && vals && g && W_dec && exp_avg && exp_avg_sq && h_host,
                 "mtc_fused_backward_adam_dec: null pointer");
@@ -320,8 +330,14 @@ extern "C" int mtc_fused_backward_adam_dec(const mtc_desc* d, const int32_t* col
     const int A = d->A_t;
     const void* coef = vals; const void* src = g;
     void* W = W_dec; void* m = exp_avg; void* v = exp_avg_sq; void* bias = nullptr; void* m_b = nullptr; void* v_b = nullptr;
-    if (d->dtype == MTC_BF16) LAUNCH_FUSED(MTC_BF16, MTC_BF16, 1);
-    else LAUNCH_FUSED(MTC_F32, MTC_F32, 1);
+    float* dv_out = d_vals_out;
+    if (dv_out) {
+        if (d->dtype == MTC_BF16) LAUNCH_FUSED(MTC_BF16, MTC_BF16, 1, 1);
+        else LAUNCH_FUSED(MTC_F32, MTC_F32, 1, 1);
+    } else {
+        if (d->dtype == MTC_BF16) LAUNCH_FUSED(MTC_BF16, MTC_BF16, 1, 0);
+        else LAUNCH_FUSED(MTC_F32, MTC_F32, 1, 0);
+    }
     return check_launch("mtc_fused_backward_adam_dec");
 }
 
@@ -338,7 +354,8 @@ extern "C" int mtc_fused_backward_adam_enc(const mtc_desc* d, const int32_t* col
     const int A = d->A_s;
     const void* coef = d_vals; const void* src = x_norm;
     void* W = W_encT; void* m = exp_avg; void* v = exp_avg_sq; void* bias = b_enc; void* m_b = b_exp_avg; void* v_b = b_exp_avg_sq;
-    if (d->dtype == MTC_BF16) LAUNCH_FUSED(MTC_BF16, MTC_F32, 0);
-    else LAUNCH_FUSED(MTC_F32, MTC_F32, 0);
+    float* dv_out = nullptr; const float l1_term = 0.f;
+    if (d->dtype == MTC_BF16) LAUNCH_FUSED(MTC_BF16, MTC_F32, 0, 0);
+    else LAUNCH_FUSED(MTC_F32, MTC_F32, 0, 0);
     return check_launch("mtc_fused_backward_adam_enc");
 }

@@ -63,6 +63,27 @@ template <> __device__ __forceinline__ void store_raw<MTC_F32>(void* base, size_
     p[0] = r.a; p[1] = r.b;
 }
 
+// p += a . b over one chunk of 8 elements in storage form.  bf16: v_dot2c_f32_bf16 on the packed
+// pairs (no unpacking; 4 instructions per chunk); fp32: an fma chain.
+__device__ __forceinline__ float dot_chunk(const Raw<MTC_BF16>& a, const Raw<MTC_BF16>& b, float p) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t ai = a.v[i], bi = b.v[i];     // (bit_cast of a vector ELEMENT lvalue reads element 0: copy first)
+        p = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, ai), __builtin_bit_cast(bf16x2, bi), p, false);
+    }
+    return p;
+}
+__device__ __forceinline__ float dot_chunk(const Raw<MTC_F32>& a, const Raw<MTC_F32>& b, float p) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) p = fmaf(a.a[i], b.a[i], p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) p = fmaf(a.b[i], b.b[i], p);
+    return p;
+}
+template <int DT> __device__ __forceinline__ Raw<DT> zero_raw();
+template <> __device__ __forceinline__ Raw<MTC_BF16> zero_raw<MTC_BF16>() { Raw<MTC_BF16> r; r.v = u32x4{0, 0, 0, 0}; return r; }
+template <> __device__ __forceinline__ Raw<MTC_F32> zero_raw<MTC_F32>() { Raw<MTC_F32> r; r.a = f32x4{0, 0, 0, 0}; r.b = r.a; return r; }
+
 // rows kept in flight per lane: about 8-10 16-byte loads, bounded so that acc (8 NC) + raw rows
 // (4 U NC) stay near 128 VGPRs (4 waves per SIMD)
 #ifndef MTC_GATHER_U5
@@ -152,23 +173,18 @@ __device__ __forceinline__ void accumulate_run(const RowCtx<DT, NC>& rc, const v
     accumulate_run_u<DT, NC, gather_u(NC)>(rc, W, A, my_col, my_val, i0, n, acc);
 }
 
-// d_vals_out[i] = g . W[j_i] + l1_term for the `n` (<= 64) entries whose columns sit in my_col.
-// Four rows at a time; the four per-lane partials are folded with 7 cross-lane exchanges
-// (halve the value set while halving the lane set) instead of 4 x 6.  g of chunks beyond the row is
-// treated as zero.
+// d_vals_out[i] = g . W[j_i] + l1_term for the `n` (<= 64) entries whose columns sit in my_col; g is
+// the row in storage form (model dtype, zero in chunks beyond the row).  Four rows at a time; the four
+// per-lane partials are folded with 7 cross-lane exchanges (halve the value set while halving the lane
+// set) instead of 4 x 6.
 template <int DT, int NC>
 __device__ __forceinline__ void dot_run(const RowCtx<DT, NC>& rc, const void* __restrict__ W, int A, int my_col,
-                                        int n, const float (&g_in)[NC][8], float l1_term, float* __restrict__ d_vals_out) {
+                                        int n, const Raw<DT> (&g)[NC], float l1_term, float* __restrict__ d_vals_out) {
     const uint32_t row_bytes = (uint32_t)A * (uint32_t)sizeof(typename DType<DT>::T);
     const int lane = rc.lane;
     uint32_t co[NC];
     chunk_byte_offsets(rc, co);
     const rsrc_t Wb = make_rsrc(W);
-    float g[NC][8];
-#pragma unroll
-    for (int c = 0; c < NC; ++c)
-#pragma unroll
-        for (int k = 0; k < 8; ++k) g[c][k] = rc.valid(c) ? g_in[c][k] : 0.f;
     int i = 0;
     constexpr int UD = gather_u(NC) >= 4 ? 4 : gather_u(NC);
     for (; i + 4 <= n; i += 4) {
@@ -177,18 +193,12 @@ __device__ __forceinline__ void dot_run(const RowCtx<DT, NC>& rc, const void* __
         for (int h = 0; h < 4; h += UD) {
             Raw<DT> r[UD][NC];
 #pragma unroll
-            for (int u = 0; u < UD; ++u) {
+            for (int u = 0; u < UD; ++u)
                 load_row<DT, NC>(Wb, row_bytes, __builtin_amdgcn_readlane(my_col, i + h + u), co, r[u]);
-            }
 #pragma unroll
             for (int u = 0; u < UD; ++u)
 #pragma unroll
-                for (int c = 0; c < NC; ++c) {
-                    float w[8];
-                    unpack(r[u][c], w);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) p[h + u] = fmaf(g[c][k], w[k], p[h + u]);
-                }
+                for (int c = 0; c < NC; ++c) p[h + u] = dot_chunk(g[c], r[u][c], p[h + u]);
         }
         // lanes < 32 keep entries {0,1}, lanes >= 32 keep {2,3}
         const bool hi = lane >= 32;
@@ -208,14 +218,71 @@ __device__ __forceinline__ void dot_run(const RowCtx<DT, NC>& rc, const void* __
         load_row<DT, NC>(Wb, row_bytes, __builtin_amdgcn_readlane(my_col, i), co, r1);
         float p = 0.f;
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            float w[8];
-            unpack(r1[c], w);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) p = fmaf(g[c][k], w[k], p);
-        }
+        for (int c = 0; c < NC; ++c) p = dot_chunk(g[c], r1[c], p);
         p = wave_sum(p);
         if (lane == 0) d_vals_out[i] = p + l1_term;
+    }
+}
+
+// acc += a * g_row and returns this lane's share of g_row . w (w in storage form)
+template <int DT, int NC>
+__device__ __forceinline__ float fma_dot_row(const Raw<DT> (&r)[NC], float a, const Raw<DT> (&w)[NC], float (&acc)[NC][8]) {
+    float pp = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        pp = dot_chunk(r[c], w[c], pp);
+        float gv[8];
+        unpack(r[c], gv);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[c][k] = fmaf(a, gv[k], acc[c][k]);
+    }
+    return pp;
+}
+
+// Decoder-side backward of one feature j over its `n` (<= 64) lane-resident entries (rows / coefs /
+// CSR positions): ONE gather of g_b serves both  acc += a_bj g_b  (the W_dec[j] gradient) and
+// d a_bj = g_b . W_dec[j] + l1_term  (written to d_vals_out[pos]; the per-row second sweep of the
+// decode kernel re-gathered W_dec for it).  `w` is the feature's W_dec row in storage form.  Same per-lane FMA order
+// and the same reduction tree as dot_run, so the values are bit-identical to it.
+template <int DT, int NC>
+__device__ __forceinline__ void accumulate_dot_run(const RowCtx<DT, NC>& rc, const void* __restrict__ src, int A,
+                                                   int my_row, float my_c, int my_pos, int n_, const Raw<DT> (&w)[NC],
+                                                   float l1_term, float* __restrict__ d_vals_out, float (&acc)[NC][8]) {
+    const int n = __builtin_amdgcn_readfirstlane(n_);
+    if (n <= 0) return;
+    const int lane = rc.lane, last = n - 1;
+    const uint32_t row_bytes = (uint32_t)A * (uint32_t)sizeof(typename DType<DT>::T);
+    uint32_t co[NC];
+    chunk_byte_offsets(rc, co);
+    const rsrc_t rs = make_rsrc(src);
+#pragma unroll 1
+    for (int i = 0; i < n; i += 4) {
+        float p[4];
+#pragma unroll
+        for (int h = 0; h < 4; h += 2) {
+            Raw<DT> r[2][NC];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)      // entries past the end re-request the last row (coefficient 0, result unused)
+                load_row<DT, NC>(rs, row_bytes, __builtin_amdgcn_readlane(my_row, min(i + h + u, last)), co, r[u]);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int cur = i + h + u;
+                float a = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_c), min(cur, last)));
+                a = cur < n ? a : 0.f;
+                p[h + u] = fma_dot_row<DT, NC>(r[u], a, w, acc);
+            }
+        }
+        const bool hi = lane >= 32;
+        const float s0 = hi ? p[0] : p[2], s1 = hi ? p[1] : p[3];
+        const float k0 = (hi ? p[2] : p[0]) + __shfl_xor(s0, 32, 64);
+        const float k1 = (hi ? p[3] : p[1]) + __shfl_xor(s1, 32, 64);
+        const bool odd = (lane & 16) != 0;
+        float v = (odd ? k1 : k0) + __shfl_xor(odd ? k0 : k1, 16, 64);
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        const int e = i + 2 * (lane >> 5) + ((lane >> 4) & 1);
+        const int pos = __shfl(my_pos, min(e, last), 64);
+        if ((lane & 15) == 0 && e < n) d_vals_out[pos] = v + l1_term;
     }
 }
 

@@ -276,8 +276,12 @@ class HotPath:
               "mtc_adam_flat")
 
     def fused_backward_adam(self, d, sel: Selection, g, d_vals, x_norm, scale, W_dec, st_dec, W_encT, st_enc, b_enc,
-                            st_benc, h_dec: AdamHyper, h_enc: AdamHyper, h_benc: AdamHyper):
-        """a11 + a12 + a13 in two launches; st_* = (exp_avg, exp_avg_sq) in the storage layout of the parameter."""
+                            st_benc, h_dec: AdamHyper, h_enc: AdamHyper, h_benc: AdamHyper, l1_term: float = 0.0):
+        """a11 + a12 + a13 in two launches; st_* = (exp_avg, exp_avg_sq) in the storage layout of the parameter.
+        d_vals=None: the decoder launch also produces d a_bj (the forward skipped its second sweep)."""
+        dv_out = None
+        if d_vals is None:
+            d_vals = dv_out = torch.empty(max(sel.col_idx.numel(), 1), dtype=torch.float32, device=g.device)
         if scale is not None:
             scale = scale.reshape(1).to(torch.float32).contiguous()
         for t, n, shp in ((W_dec, "W_dec", (self.D, self.A_t)), (st_dec[0], "exp_avg(W_dec)", (self.D, self.A_t)),
@@ -288,7 +292,8 @@ class HotPath:
             _need(t, n, self.dtype, shp)
         s = _stream()
         check(self.lib.mtc_fused_backward_adam_dec(C.byref(d), _p(sel.col_ptr), _p(sel.csc_row), _p(sel.csc_pos), _p(sel.vals),
-                                                   _p(g), _p(scale), _p(W_dec), _p(st_dec[0]), _p(st_dec[1]), C.byref(h_dec), s),
+                                                   _p(g), _p(scale), _p(W_dec), _p(st_dec[0]), _p(st_dec[1]), C.byref(h_dec),
+                                                   _p(dv_out), float(l1_term), s),
               "mtc_fused_backward_adam_dec")
         if h_enc.step != h_benc.step or h_enc.lr != h_benc.lr:
             raise _lib.MtcError("W_enc and b_enc must share one Adam step count / lr for the fused update")

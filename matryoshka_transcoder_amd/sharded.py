@@ -236,7 +236,7 @@ class ShardedMatryoshkaTranscoder(MatryoshkaTranscoder):
         g = both[:, 1].reshape(B, A_t).contiguous()
         row_stats = self.comm.all_gather(stats_l).permute(1, 0, 2).reshape(G + 4, B).contiguous()
         l1_term = float(cfg["l1_coeff"]) / (B * self.total_dict_size)
-        d_vals = hp.decode_bwd_vals(d, sel, W_dec, g, l1_term) if need_grad else None
+        d_vals = hp.decode_bwd_vals(d, sel, W_dec, g, l1_term) if need_grad and not getattr(self, "_defer_dvals", False) else None
         scalars = hp.reduce_scalars(d, row_stats, sel, self.total_dict_size, float(cfg["l1_coeff"]),
                                     float(cfg["aux_penalty"]), nnz_abs_override=nnz_abs)
         return x_hat.contiguous(), g, d_vals, row_stats, scalars, None

@@ -75,7 +75,11 @@ class FusedAdam(torch.optim.Optimizer):
         tc = self.transcoder
         if not tc.training:
             raise _lib.MtcError("train_step() needs the transcoder in training mode")
-        res = tc._run_forward(x_source, x_target, tc.W_enc, tc.b_enc, tc.W_dec, tc.b_dec, True)
+        tc._defer_dvals = True          # d a_bj comes out of the decoder-gradient kernel below
+        try:
+            res = tc._run_forward(x_source, x_target, tc.W_enc, tc.b_enc, tc.W_dec, tc.b_dec, True)
+        finally:
+            tc._defer_dvals = False
         tc._last_res = res
         out = tc._output_dict(res, x_target)
         hp = tc.hot_path()
@@ -100,7 +104,8 @@ class FusedAdam(torch.optim.Optimizer):
             m_e, v_e = se["exp_avg"].t(), se["exp_avg_sq"].t()
         hp.fused_backward_adam(res.desc, res.sel, res.g, res.d_vals, res.x_norm, None, tc.W_dec.data,
                                (sd["exp_avg"], sd["exp_avg_sq"]), W_encT.data, (m_e, v_e), tc.b_enc.data,
-                               (sb["exp_avg"], sb["exp_avg_sq"]), hy["W_dec"], hy["W_enc"], hy["b_enc"])
+                               (sb["exp_avg"], sb["exp_avg_sq"]), hy["W_dec"], hy["W_enc"], hy["b_enc"],
+                               l1_term=float(tc.config["l1_coeff"]) / (res.desc.B * tc.total_dict_size))
         db_dec = hp.colsum(res.desc, res.g)
         hp.adam_flat(tc.b_dec.data, db_dec, sbd["exp_avg"], sbd["exp_avg_sq"], hy["b_dec"])
         return out

@@ -224,12 +224,11 @@ class MatryoshkaTranscoder(nn.Module):
         """a6-a10: decode + losses (+ aux).  Overridden by the feature-sharded model."""
         cfg = self.config
         l1_term = float(cfg["l1_coeff"]) / (d.B * self.total_dict_size)
-        split = False        # fused second sweep measured faster than a separate mtc_decode_bwd_vals launch
+        # FusedAdam.train_step defers d a_bj to the decoder-gradient kernel (one gather of g serves both)
+        defer = getattr(self, "_defer_dvals", False)
         x_hat, g, row_stats, _, d_vals = hp.decode(
             d, sel, W_dec, b_dec, x_target, mean, std, want_g=need_grad or aux_active,
-            want_dvals=need_grad and not aux_active and not split, l1_term=l1_term)
-        if split and need_grad and not aux_active:
-            d_vals = hp.decode_bwd_vals(d, sel, W_dec, g, l1_term)
+            want_dvals=need_grad and not aux_active and not defer, l1_term=l1_term)
         aux = None
         aux_rows = None
         if aux_active:

@@ -70,6 +70,8 @@ def main():
         "backward": lambda: hp.backward(d, sel, g, d_vals, xs, None),
         "fused_backward_adam": lambda: hp.fused_backward_adam(
             d, sel, g, d_vals, xs, None, W_dec, (m, v), W_encT, (m2, v2), b_enc, (mb, vb), h, h, h),
+        "fused_backward_adam_dvals": lambda: hp.fused_backward_adam(
+            d, sel, g, None, xs, None, W_dec, (m, v), W_encT, (m2, v2), b_enc, (mb, vb), h, h, h),
         "unitnorm_adam": lambda: hp.unitnorm_adam(W_dec, grads[0], m, v, h, write_grad=False),
         "adam_flat": lambda: hp.adam_flat(W_dec, grads[0], m, v, h),
     }
