@@ -115,6 +115,20 @@ int mtc_select_global_topk(const mtc_desc* d, const void* acts, uint32_t k_total
                            size_t workspace_bytes, mtc_select_state* st, int32_t* row_ptr,
                            int32_t* col_idx, void* vals, void* stream);
 
+/* Training-loop variant of mtc_select_global_topk (TopK mode only; same outputs, bit for bit).
+ * tau moves slowly between steps (sae.py:176-187 runs once per step on weights one Adam update
+ * apart), so `carry` -- 8 uint32 on the device, zeroed once by the caller and then left alone --
+ * keeps the previous tau minus a margin as a lower bound.  One pass over acts copies the entries
+ * >= bound into a compact [B][min(D,1024)] matrix and the exact select runs on that; if the bound
+ * turns out wrong (too few candidates, or a row with more than fit) the full-size passes run
+ * instead.  Both sets of launches are enqueued and predicated on a device flag: no read-back.
+ * carry[4] / carry[5] count the calls served by the compact / full path. */
+size_t mtc_select_carry_workspace_bytes(const mtc_desc* d);
+int mtc_select_global_topk_carry(const mtc_desc* d, const void* acts, uint32_t k_total,
+                                 void* workspace, size_t workspace_bytes, uint32_t* carry,
+                                 mtc_select_state* st, int32_t* row_ptr, int32_t* col_idx,
+                                 void* vals, void* stream);
+
 /* a5  update_threshold (sae.py:349-361): threshold <- (1-lr)*threshold + lr*min_selected, evaluated
  * in the buffer dtype, skipped when nothing was selected. */
 int mtc_threshold_ema(const mtc_desc* d, const mtc_select_state* st, void* threshold, float lr,

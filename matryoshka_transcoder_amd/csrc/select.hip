@@ -18,6 +18,15 @@ namespace mtc {
 
 constexpr int HIST_BINS = 4096;
 
+// min over all selected values, one candidate per wave.  4096 same-address atomics serialise in L2
+// (~40 us), so a wave first looks at the current value: it only ever decreases, hence a stale read
+// can cost a redundant atomic but never skips a needed one.
+__device__ __forceinline__ void note_min_selected(mtc_select_state* st, uint32_t mn) {
+    if (mn == 0xffffffffu) return;
+    const uint32_t cur = __hip_atomic_load(&st->min_sel_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (mn < cur) atomicMin(&st->min_sel_bits, mn);
+}
+
 __device__ __forceinline__ int level_shift(int level) { return level == 0 ? 19 : (level == 1 ? 7 : 0); }
 __device__ __forceinline__ uint32_t level_mask(int level) { return level == 2 ? 0x7fu : 0xfffu; }
 // bits above the level's field (must match the prefix fixed so far)
@@ -36,8 +45,10 @@ __global__ void select_init_kernel(mtc_select_state* st, uint32_t k_total) {
 template <int DT>
 __global__ __launch_bounds__(256) void select_hist_kernel(const void* __restrict__ acts, size_t n_chunks, int level,
                                                           const mtc_select_state* __restrict__ st,
-                                                          uint32_t* __restrict__ hist) {
+                                                          uint32_t* __restrict__ hist,
+                                                          const uint32_t* __restrict__ pred, uint32_t want) {
     __shared__ uint32_t lh[HIST_BINS];
+    if (pred && *pred != want) return;                 // uniform: the other of the compact / full paths runs
     for (int i = threadIdx.x; i < HIST_BINS; i += 256) lh[i] = 0;
     __syncthreads();
     const uint32_t all_pos = st->all_pos;
@@ -122,10 +133,12 @@ template <int DT>
 __global__ __launch_bounds__(256) void select_count_kernel(const void* __restrict__ acts, int B, int D,
                                                            mtc_select_state* __restrict__ st,
                                                            const void* __restrict__ threshold,
-                                                           uint32_t* __restrict__ row_gt, uint32_t* __restrict__ row_eq) {
+                                                           uint32_t* __restrict__ row_gt, uint32_t* __restrict__ row_eq,
+                                                           const uint32_t* __restrict__ pred, uint32_t want) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= B) return;
+    if (pred && *pred != want) return;
     float tau; bool ties = false, nz = false;
     if (threshold) {
         tau = DType<DT>::ld(reinterpret_cast<const typename DType<DT>::T*>(threshold));
@@ -158,7 +171,7 @@ __global__ __launch_bounds__(256) void select_count_kernel(const void* __restric
     for (int o = 32; o > 0; o >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, o, 64));
     if (lane == 0) {
         row_gt[row] = gt; row_eq[row] = eq;
-        if (mn != 0xffffffffu) atomicMin(&st->min_sel_bits, mn);
+        note_min_selected(st, mn);
     }
 }
 
@@ -168,10 +181,12 @@ __global__ __launch_bounds__(256) void select_count_kernel(const void* __restric
 __global__ __launch_bounds__(256) void select_rowsub_bf16_kernel(const void* __restrict__ acts, int B, int D,
                                                                  mtc_select_state* __restrict__ st,
                                                                  uint32_t* __restrict__ row_above,
-                                                                 uint32_t* __restrict__ row_sub /* [B][8] */) {
+                                                                 uint32_t* __restrict__ row_sub /* [B][8] */,
+                                                                 const uint32_t* __restrict__ pred, uint32_t want) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= B) return;
+    if (pred && *pred != want) return;
     const bool all_pos = st->all_pos != 0;
     const uint32_t bin = st->key_prefix >> 19;            // level-0 bin of tau
     const size_t base = (size_t)row * D;
@@ -212,7 +227,7 @@ __global__ __launch_bounds__(256) void select_rowsub_bf16_kernel(const void* __r
         row_above[row] = above;
 #pragma unroll
         for (int q = 0; q < 8; ++q) row_sub[(size_t)row * 8 + q] = sub[q];
-        if (mn != 0xffffffffu) atomicMin(&st->min_sel_bits, mn);
+        note_min_selected(st, mn);
     }
 }
 
@@ -294,7 +309,7 @@ __global__ __launch_bounds__(1024) void select_offsets_kernel(int B, const uint3
                                                               const uint32_t* __restrict__ row_eq,
                                                               const uint32_t* __restrict__ tie_before_in,
                                                               mtc_select_state* st, int32_t* __restrict__ row_ptr,
-                                                              uint32_t* __restrict__ tie_take) {
+                                                              uint32_t* __restrict__ tie_take, uint32_t* carry) {
     __shared__ uint32_t sm[16];
     const int t = threadIdx.x;
     const int per = (B + 1023) / 1024;
@@ -326,6 +341,14 @@ __global__ __launch_bounds__(1024) void select_offsets_kernel(int B, const uint3
         row_ptr[B] = (int32_t)nnz_total;
         st->nnz = nnz_total;
         if (quota > 0) st->min_sel_bits = min(st->min_sel_bits, st->tau_bits);
+        if (carry) {
+            // next step's lower bound = tau lowered by 8 bf16 ulps (about 6 %); none if tau is undefined
+            const uint32_t margin = 8u << 16;
+            uint32_t g = 0;
+            if (!st->all_pos && nnz_total != 0 && st->tau_bits > margin + 0x00800000u && st->tau_bits <= 0x7f800000u)
+                g = st->tau_bits - margin;
+            carry[0] = g;
+        }
     }
 }
 
@@ -336,11 +359,14 @@ __global__ __launch_bounds__(256) void select_fill_kernel(const void* __restrict
                                                           const void* __restrict__ threshold,
                                                           const int32_t* __restrict__ row_ptr,
                                                           const uint32_t* __restrict__ tie_take,
-                                                          int32_t* __restrict__ col_idx, void* __restrict__ vals) {
+                                                          int32_t* __restrict__ col_idx, void* __restrict__ vals,
+                                                          const int32_t* __restrict__ col_map /* [B][D] or null */,
+                                                          const uint32_t* __restrict__ pred, uint32_t want) {
     typedef typename DType<DT>::T T;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= B) return;
+    if (pred && *pred != want) return;
     float tau; uint32_t quota = 0; bool nz = false;
     if (threshold) {
         tau = DType<DT>::ld(reinterpret_cast<const T*>(threshold));
@@ -395,12 +421,125 @@ __global__ __launch_bounds__(256) void select_fill_kernel(const void* __restrict
 #pragma unroll
             for (int i = 0; i < 8; ++i)
                 if (selm & (1u << i)) {
-                    col_idx[pos] = c * 8 + i;
+                    col_idx[pos] = col_map ? col_map[base + (size_t)c * 8 + i] : c * 8 + i;
                     DType<DT>::st(vout + pos, v[i]);
                     ++pos;
                 }
             out += __shfl(inc, 63, 64);
         }
+    }
+}
+
+// ---------------------------------------------------------------- carried lower bound (training loop)
+// tau moves slowly from one training step to the next.  With a lower bound `guess` (the previous
+// step's tau minus a margin) ONE pass over acts copies every entry >= guess into a compact
+// [B][C] matrix (+ its column map), in row / ascending-column order; the exact select above then runs
+// on that matrix (a few MB) instead of three more passes over B*D activations.  The result is
+// identical: every entry >= tau is a candidate and order is preserved, so tau, the tie quota and
+// the tie order come out the same.  If the bound was wrong (fewer than k candidates, or a row with
+// more than C) the flag stays 0 and the full-size passes run instead -- both sets of launches are
+// enqueued, each predicated on the device-side flag, so nothing is read back.
+//   carry[0] guess bits (0 = none)  [1] flag: 1 = compact path valid  [2] candidates  [3] overflow
+//   carry[4] calls served by the compact path  [5] calls served by the full path
+__device__ __forceinline__ uint32_t mbcnt64(uint64_t m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void select_candidates_kernel(const void* __restrict__ acts, int B, int D, int C,
+                                                                const uint32_t* __restrict__ carry, void* __restrict__ cand_vals,
+                                                                int32_t* __restrict__ cand_cols, uint32_t* __restrict__ cand_cnt) {
+    typedef typename DType<DT>::T T;
+    constexpr int U = DT == MTC_BF16 ? 8 : 4;
+    const int lane = threadIdx.x & 63;
+    const int row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (row >= B) return;
+    const uint32_t guess = carry[0];
+    if (guess == 0) return;
+    const size_t base = (size_t)row * D;
+    T* vout = reinterpret_cast<T*>(cand_vals) + (size_t)row * C;
+    int32_t* cout = cand_cols + (size_t)row * C;
+    const int nch = D >> 3;
+    uint32_t out = 0;
+    Raw<DT> nxt[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        if (64 * u + lane < nch) nxt[u] = load_raw<DT>(acts, base + (size_t)(64 * u + lane) * 8);
+    for (int cb = 0; cb < nch; cb += 64 * U) {
+        Raw<DT> cur[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+        const int nb = cb + 64 * U;                    // next block is requested before this one is scanned
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (nb + 64 * u + lane < nch) nxt[u] = load_raw<DT>(acts, base + (size_t)(nb + 64 * u + lane) * 8);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (cb + 64 * u >= nch) break;                   // wave-uniform
+            const int c = cb + 64 * u + lane;
+            float v[8];
+            uint32_t m = 0;
+            if (c < nch) {
+                unpack(cur[u], v);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const uint32_t k = __float_as_uint(v[i]);
+                    if (k >= guess && k <= 0x7f800000u) m |= 1u << i;
+                }
+            }
+            if (__ballot(m != 0) == 0) continue;             // wave-uniform
+            // exclusive prefix of popc(m) over the lanes from ballots of its bit planes (most lanes hold 0 or 1)
+            const uint32_t ns = __popc(m);
+            const uint64_t b0 = __ballot((ns & 1u) != 0), b1 = __ballot((ns & 2u) != 0);
+            const uint64_t b2 = __ballot((ns & 4u) != 0), b3 = __ballot((ns & 8u) != 0);
+            uint32_t pos = out + mbcnt64(b0);
+            uint32_t tot = (uint32_t)__popcll(b0);
+            if (b1) { pos += 2u * mbcnt64(b1); tot += 2u * (uint32_t)__popcll(b1); }
+            if (b2) { pos += 4u * mbcnt64(b2); tot += 4u * (uint32_t)__popcll(b2); }
+            if (b3) { pos += 8u * mbcnt64(b3); tot += 8u * (uint32_t)__popcll(b3); }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (m & (1u << i)) {
+                    if (pos < (uint32_t)C) { DType<DT>::st(vout + pos, v[i]); cout[pos] = c * 8 + i; }
+                    ++pos;
+                }
+            out += tot;
+        }
+    }
+    // zero the unused tail of the compact row (the select passes treat 0 as "not a candidate")
+    const uint32_t n_kept = min(out, (uint32_t)C);
+    const uint32_t al = (n_kept + 7u) & ~7u;
+    if (n_kept + lane < al) DType<DT>::st(vout + n_kept + lane, 0.f);
+    const float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t ch = (al >> 3) + lane; ch < (uint32_t)(C >> 3); ch += 64) store8<DT>(vout, (size_t)ch * 8, z);
+    if (lane == 0) cand_cnt[row] = out;
+}
+
+// one workgroup, after the candidate pass: total / overflow from the per-row counts -> which path is valid
+// (also what mtc_select_init and the histogram memset do, to save two launches)
+__global__ __launch_bounds__(1024) void select_carry_decide_kernel(uint32_t* carry, const uint32_t* __restrict__ cand_cnt, int B, int C,
+                                                                   uint32_t k_total, mtc_select_state* st,
+                                                                   uint32_t* __restrict__ hist) {
+    __shared__ uint32_t s_tot[16], s_over[16];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    for (int i = t; i < 3 * HIST_BINS; i += 1024) hist[i] = 0;
+    if (t == 0) {
+        st->key_prefix = 0; st->k_rem = k_total; st->all_pos = 0; st->n_gt = 0;
+        st->tau_bits = 0; st->n_tie_take = 0; st->min_sel_bits = 0xffffffffu; st->nnz = 0;
+        for (int i = 0; i < 8; ++i) st->pad[i] = 0;
+    }
+    uint32_t tot = 0, over = 0;
+    if (carry[0] != 0)
+        for (int r = t; r < B; r += 1024) { const uint32_t n = cand_cnt[r]; tot += n; over |= n > (uint32_t)C ? 1u : 0u; }
+    tot = wave_sum_u32(tot); over = wave_sum_u32(over);
+    if (lane == 0) { s_tot[w] = tot; s_over[w] = over; }
+    __syncthreads();
+    if (t == 0) {
+        tot = 0; over = 0;
+        for (int i = 0; i < 16; ++i) { tot += s_tot[i]; over += s_over[i]; }
+        const uint32_t ok = (carry[0] != 0 && tot >= k_total && over == 0) ? 1u : 0u;
+        carry[1] = ok; carry[2] = tot; carry[3] = over;
+        carry[4] += ok; carry[5] += 1u - ok;
     }
 }
 
@@ -456,15 +595,22 @@ extern "C" int mtc_select_init(mtc_select_state* st, uint32_t k_total, void* str
     return check_launch("mtc_select_init");
 }
 
+// `cols` = row length of the matrix the pass streams (D, or C for the compact candidate matrix)
+static int hist_impl(const mtc_desc* d, int cols, const void* acts, int level, const mtc_select_state* st, uint32_t* hist,
+                     const uint32_t* pred, uint32_t want, void* stream) {
+    const size_t n_chunks = (size_t)d->B * cols / 8;
+    // every workgroup zeroes and flushes a 4096-bin LDS histogram: give each at least 16 chunks per thread
+    const int grid = (int)std::max<size_t>(1, std::min<size_t>((n_chunks + 256 * 16 - 1) / (256 * 16), 2048));
+    DISPATCH_DT(d->dtype, select_hist_kernel, dim3(grid), dim3(256), 0, as_stream(stream), acts, n_chunks, level, st, hist,
+                pred, want);
+    return check_launch("mtc_select_hist");
+}
 extern "C" int mtc_select_hist(const mtc_desc* d, const void* acts, int level, const mtc_select_state* st,
                                uint32_t* hist, void* stream) {
     if (check_desc(d, "mtc_select_hist")) return -1;
     MTC_REQUIRE(acts && st && hist, "mtc_select_hist: null pointer");
     MTC_REQUIRE(level >= 0 && level < mtc_select_levels(d), "mtc_select_hist: bad level %d", level);
-    const size_t n_chunks = (size_t)d->B * d->D / 8;
-    const int grid = (int)std::min<size_t>((n_chunks + 255) / 256, 2048);
-    DISPATCH_DT(d->dtype, select_hist_kernel, dim3(grid), dim3(256), 0, as_stream(stream), acts, n_chunks, level, st, hist);
-    return check_launch("mtc_select_hist");
+    return hist_impl(d, d->D, acts, level, st, hist, nullptr, 0, stream);
 }
 
 extern "C" int mtc_select_scan(const mtc_desc* d, int level, const uint32_t* hist, mtc_select_state* st, void* stream) {
@@ -475,43 +621,60 @@ extern "C" int mtc_select_scan(const mtc_desc* d, int level, const uint32_t* his
     return check_launch("mtc_select_scan");
 }
 
+static int count_impl(const mtc_desc* d, int cols, const void* acts, const mtc_select_state* st, const void* threshold,
+                      uint32_t* row_gt, uint32_t* row_eq, const uint32_t* pred, uint32_t want, void* stream) {
+    DISPATCH_DT(d->dtype, select_count_kernel, dim3((d->B + 3) / 4), dim3(256), 0, as_stream(stream), acts, d->B, cols,
+                const_cast<mtc_select_state*>(st), threshold, row_gt, row_eq, pred, want);
+    return check_launch("mtc_select_count");
+}
 extern "C" int mtc_select_count(const mtc_desc* d, const void* acts, const mtc_select_state* st, const void* threshold,
                                 uint32_t* row_gt, uint32_t* row_eq, void* stream) {
     if (check_desc(d, "mtc_select_count")) return -1;
     MTC_REQUIRE(acts && st && row_gt && row_eq, "mtc_select_count: null pointer");
-    DISPATCH_DT(d->dtype, select_count_kernel, dim3((d->B + 3) / 4), dim3(256), 0, as_stream(stream), acts, d->B, d->D,
-                const_cast<mtc_select_state*>(st), threshold, row_gt, row_eq);
-    return check_launch("mtc_select_count");
+    return count_impl(d, d->D, acts, st, threshold, row_gt, row_eq, nullptr, 0, stream);
 }
 
+static int offsets_impl(const mtc_desc* d, const uint32_t* row_gt, const uint32_t* row_eq, const uint32_t* tie_before,
+                        mtc_select_state* st, int32_t* row_ptr, uint32_t* tie_take, uint32_t* carry, void* stream) {
+    hipLaunchKernelGGL(select_offsets_kernel, dim3(1), dim3(1024), 0, as_stream(stream), d->B, row_gt, row_eq,
+                       tie_before, st, row_ptr, tie_take, carry);
+    return check_launch("mtc_select_offsets");
+}
 extern "C" int mtc_select_offsets(const mtc_desc* d, const uint32_t* row_gt, const uint32_t* row_eq,
                                   const uint32_t* tie_before, mtc_select_state* st, int32_t* row_ptr,
                                   uint32_t* tie_take, void* stream) {
     if (check_desc(d, "mtc_select_offsets")) return -1;
     MTC_REQUIRE(row_gt && row_eq && st && row_ptr && tie_take, "mtc_select_offsets: null pointer");
-    hipLaunchKernelGGL(select_offsets_kernel, dim3(1), dim3(1024), 0, as_stream(stream), d->B, row_gt, row_eq,
-                       tie_before, st, row_ptr, tie_take);
-    return check_launch("mtc_select_offsets");
+    return offsets_impl(d, row_gt, row_eq, tie_before, st, row_ptr, tie_take, nullptr, stream);
 }
 
+static int fill_impl(const mtc_desc* d, int cols, const void* acts, const mtc_select_state* st, const void* threshold,
+                     const int32_t* row_ptr, const uint32_t* tie_take, int32_t* col_idx, void* vals, const int32_t* col_map,
+                     const uint32_t* pred, uint32_t want, void* stream) {
+    DISPATCH_DT(d->dtype, select_fill_kernel, dim3((d->B + 3) / 4), dim3(256), 0, as_stream(stream), acts, d->B, cols,
+                st, threshold, row_ptr, tie_take, col_idx, vals, col_map, pred, want);
+    return check_launch("mtc_select_fill");
+}
 extern "C" int mtc_select_fill(const mtc_desc* d, const void* acts, const mtc_select_state* st, const void* threshold,
                                const int32_t* row_ptr, const uint32_t* tie_take, int32_t* col_idx, void* vals,
                                void* stream) {
     if (check_desc(d, "mtc_select_fill")) return -1;
     MTC_REQUIRE(acts && st && row_ptr && tie_take && col_idx && vals, "mtc_select_fill: null pointer");
-    DISPATCH_DT(d->dtype, select_fill_kernel, dim3((d->B + 3) / 4), dim3(256), 0, as_stream(stream), acts, d->B, d->D,
-                st, threshold, row_ptr, tie_take, col_idx, vals);
-    return check_launch("mtc_select_fill");
+    return fill_impl(d, d->D, acts, st, threshold, row_ptr, tie_take, col_idx, vals, nullptr, nullptr, 0, stream);
 }
 
+static int rowsub_impl(const mtc_desc* d, int cols, const void* acts, mtc_select_state* st, uint32_t* row_above,
+                       uint32_t* row_sub, const uint32_t* pred, uint32_t want, void* stream) {
+    hipLaunchKernelGGL(select_rowsub_bf16_kernel, dim3((d->B + 3) / 4), dim3(256), 0, as_stream(stream), acts, d->B, cols, st,
+                       row_above, row_sub, pred, want);
+    return check_launch("mtc_select_rowsub");
+}
 extern "C" int mtc_select_rowsub(const mtc_desc* d, const void* acts, mtc_select_state* st, uint32_t* row_above,
                                  uint32_t* row_sub, void* stream) {
     if (check_desc(d, "mtc_select_rowsub")) return -1;
     MTC_REQUIRE(d->dtype == MTC_BF16, "mtc_select_rowsub: bf16 only (fp32 keeps 19 key bits after level 0)");
     MTC_REQUIRE(acts && st && row_above && row_sub, "mtc_select_rowsub: null pointer");
-    hipLaunchKernelGGL(select_rowsub_bf16_kernel, dim3((d->B + 3) / 4), dim3(256), 0, as_stream(stream), acts, d->B, d->D, st,
-                       row_above, row_sub);
-    return check_launch("mtc_select_rowsub");
+    return rowsub_impl(d, d->D, acts, st, row_above, row_sub, nullptr, 0, stream);
 }
 
 extern "C" int mtc_select_finish_rows(const mtc_desc* d, mtc_select_state* st, const uint32_t* row_above,
@@ -571,6 +734,70 @@ extern "C" int mtc_select_global_topk(const mtc_desc* d, const void* acts, uint3
     if ((rc = mtc_select_count(d, acts, st, threshold, row_gt, row_eq, stream))) return rc;
     if ((rc = mtc_select_offsets(d, row_gt, row_eq, nullptr, st, row_ptr, tie_take, stream))) return rc;
     return mtc_select_fill(d, acts, st, threshold, row_ptr, tie_take, col_idx, vals, stream);
+}
+
+static int carry_cols(const mtc_desc* d) { return d->D < 1024 ? d->D : 1024; }
+
+extern "C" size_t mtc_select_carry_workspace_bytes(const mtc_desc* d) {
+    if (!d) return 0;
+    const size_t es = d->dtype == MTC_BF16 ? 2 : 4;
+    const size_t cells = (size_t)d->B * carry_cols(d);
+    return ((mtc_select_workspace_bytes(d) + 255) & ~(size_t)255) + ((cells * es + 255) & ~(size_t)255) +
+           ((cells * sizeof(int32_t) + 255) & ~(size_t)255) + (size_t)d->B * sizeof(uint32_t);
+}
+
+extern "C" int mtc_select_global_topk_carry(const mtc_desc* d, const void* acts, uint32_t k_total, void* workspace,
+                                            size_t workspace_bytes, uint32_t* carry, mtc_select_state* st,
+                                            int32_t* row_ptr, int32_t* col_idx, void* vals, void* stream) {
+    if (check_desc(d, "mtc_select_global_topk_carry")) return -1;
+    MTC_REQUIRE(acts && workspace && carry && st && row_ptr && col_idx && vals, "mtc_select_global_topk_carry: null pointer");
+    MTC_REQUIRE(workspace_bytes >= mtc_select_carry_workspace_bytes(d),
+                "mtc_select_global_topk_carry: workspace too small (%zu < %zu)", workspace_bytes,
+                mtc_select_carry_workspace_bytes(d));
+    hipStream_t s = as_stream(stream);
+    const int C = carry_cols(d);
+    const size_t es = d->dtype == MTC_BF16 ? 2 : 4;
+    char* ws = reinterpret_cast<char*>(workspace);
+    uint32_t* hist = reinterpret_cast<uint32_t*>(ws);
+    const size_t bpad = (size_t)((d->B + 63) & ~63);
+    uint32_t* row_gt = hist + 3 * HIST_BINS;
+    uint32_t* row_eq = row_gt + bpad;
+    uint32_t* tie_take = row_eq + bpad;
+    uint32_t* row_above = tie_take + bpad;
+    uint32_t* row_sub = row_above + bpad;
+    char* cand_vals = ws + ((mtc_select_workspace_bytes(d) + 255) & ~(size_t)255);
+    int32_t* cand_cols = reinterpret_cast<int32_t*>(cand_vals + (((size_t)d->B * C * es + 255) & ~(size_t)255));
+    uint32_t* cand_cnt = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(cand_cols) +
+                                                     (((size_t)d->B * C * sizeof(int32_t) + 255) & ~(size_t)255));
+    const uint32_t* flag = carry + 1;
+    int rc;
+    // one pass over acts with the carried bound, then the verdict (flag) for the launches below
+    DISPATCH_DT(d->dtype, select_candidates_kernel, dim3((d->B + 3) / 4), dim3(256), 0, s, acts, d->B, d->D, C, carry,
+                (void*)cand_vals, cand_cols, cand_cnt);
+    hipLaunchKernelGGL(select_carry_decide_kernel, dim3(1), dim3(1024), 0, s, carry, cand_cnt, d->B, C, k_total, st, hist);
+    if ((rc = check_launch("mtc_select_global_topk_carry"))) return rc;
+    // streaming passes come in pairs (compact matrix if flag == 1, acts if flag == 0); the scans between
+    // them work on the shared histogram / per-row arrays whichever pass filled them
+    if (d->dtype == MTC_BF16) {
+        if ((rc = hist_impl(d, C, cand_vals, 0, st, hist, flag, 1, stream))) return rc;
+        if ((rc = hist_impl(d, d->D, acts, 0, st, hist, flag, 0, stream))) return rc;
+        if ((rc = mtc_select_scan(d, 0, hist, st, stream))) return rc;
+        if ((rc = rowsub_impl(d, C, cand_vals, st, row_above, row_sub, flag, 1, stream))) return rc;
+        if ((rc = rowsub_impl(d, d->D, acts, st, row_above, row_sub, flag, 0, stream))) return rc;
+        if ((rc = mtc_select_finish_rows(d, st, row_above, row_sub, nullptr, row_gt, row_eq, stream))) return rc;
+    } else {
+        const int levels = mtc_select_levels(d);
+        for (int l = 0; l < levels; ++l) {
+            if ((rc = hist_impl(d, C, cand_vals, l, st, hist + l * HIST_BINS, flag, 1, stream))) return rc;
+            if ((rc = hist_impl(d, d->D, acts, l, st, hist + l * HIST_BINS, flag, 0, stream))) return rc;
+            if ((rc = mtc_select_scan(d, l, hist + l * HIST_BINS, st, stream))) return rc;
+        }
+        if ((rc = count_impl(d, C, cand_vals, st, nullptr, row_gt, row_eq, flag, 1, stream))) return rc;
+        if ((rc = count_impl(d, d->D, acts, st, nullptr, row_gt, row_eq, flag, 0, stream))) return rc;
+    }
+    if ((rc = offsets_impl(d, row_gt, row_eq, nullptr, st, row_ptr, tie_take, carry, stream))) return rc;
+    if ((rc = fill_impl(d, C, cand_vals, st, nullptr, row_ptr, tie_take, col_idx, vals, cand_cols, flag, 1, stream))) return rc;
+    return fill_impl(d, d->D, acts, st, nullptr, row_ptr, tie_take, col_idx, vals, nullptr, flag, 0, stream);
 }
 
 extern "C" int mtc_threshold_ema(const mtc_desc* d, const mtc_select_state* st, void* threshold, float lr, void* stream) {

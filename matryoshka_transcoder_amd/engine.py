@@ -85,6 +85,7 @@ class HotPath:
         self.dtype = dtype
         self.code = dtype_code(dtype)
         self.unit_norm = bool(unit_norm)
+        self._carry = {}                 # device -> 8 x uint32 carried lower bound of the TopK threshold
 
     def desc(self, B: int):
         return _lib.make_desc(B, self.A_s, self.A_t, self.D, self.prefix, self.code, self.unit_norm)
@@ -107,15 +108,30 @@ class HotPath:
         return acts
 
     # ------------------------------------------------------------------ a3 select / a4 threshold
-    def select_topk(self, d, acts, k_total: int) -> Selection:
+    def carry_state(self, device) -> torch.Tensor:
+        key = str(device)
+        if key not in self._carry:
+            self._carry[key] = torch.zeros(8, dtype=torch.int32, device=device)
+        return self._carry[key]
+
+    def select_topk(self, d, acts, k_total: int, carry: bool = False) -> Selection:
+        """Global batch-TopK.  carry=True (training loop): use / refresh the lower bound of tau carried from
+        the previous call on this device (identical result, one pass over acts instead of three)."""
         dev = acts.device
-        ws_bytes = self.lib.mtc_select_workspace_bytes(C.byref(d))
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         st = torch.empty(16, dtype=torch.int32, device=dev)
         row_ptr = torch.empty(d.B + 1, dtype=torch.int32, device=dev)
         cap = max(int(k_total), 1)
         col_idx = torch.empty(cap, dtype=torch.int32, device=dev)
         vals = torch.empty(cap, dtype=self.dtype, device=dev)
+        if carry:
+            ws_bytes = self.lib.mtc_select_carry_workspace_bytes(C.byref(d))
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            check(self.lib.mtc_select_global_topk_carry(C.byref(d), _p(acts), int(k_total), _p(ws), ws_bytes,
+                                                        _p(self.carry_state(dev)), _p(st), _p(row_ptr), _p(col_idx),
+                                                        _p(vals), _stream()), "mtc_select_global_topk_carry")
+            return Selection(st, row_ptr, col_idx, vals)
+        ws_bytes = self.lib.mtc_select_workspace_bytes(C.byref(d))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         check(self.lib.mtc_select_global_topk(C.byref(d), _p(acts), int(k_total), None, _p(ws), ws_bytes, _p(st),
                                               _p(row_ptr), _p(col_idx), _p(vals), _stream()), "mtc_select_global_topk")
         return Selection(st, row_ptr, col_idx, vals)

@@ -174,7 +174,7 @@ class MatryoshkaTranscoder(nn.Module):
     # ------------------------------------------------------------------ the fused chain
     def _select(self, hp, d, acts, training: bool) -> Selection:
         if training:
-            sel = hp.select_topk(d, acts, int(self.config["top_k"]) * d.B)
+            sel = hp.select_topk(d, acts, int(self.config["top_k"]) * d.B, carry=True)
             hp.threshold_ema(d, sel, self.threshold)
         else:
             sel = hp.select_threshold(d, acts, self.threshold)

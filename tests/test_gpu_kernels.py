@@ -292,3 +292,63 @@ def test_dense_features_long_csc_segments(gpu_lib):
     check_against_oracle(cfg, params, cnt, xs, xt, res, hp)
     cp = res["sel"].col_ptr.cpu()
     assert int((cp[1:] - cp[:-1]).max()) == 320
+
+
+# ------------------------------------------------------------------ carried lower bound of tau (training loop select)
+def _sel_tuple(sel, nnz):
+    return (sel.state.clone(), sel.row_ptr.clone(), sel.col_idx[:nnz].clone(), sel.vals[:nnz].clone())
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_select_carry_is_identical_to_full_select(dt, gpu_lib):
+    """mtc_select_global_topk_carry must return exactly what mtc_select_global_topk returns: on the first
+    call (no bound -> full passes), with a good bound (compact path), with a bound that is too high
+    (too few candidates -> full passes) and with a row that overflows the compact matrix."""
+    from matryoshka_transcoder_amd.engine import HotPath
+    torch.manual_seed(5)
+    B, D, k = 64, 4096, 24
+    hp = HotPath(64, 64, [D], dt, False)
+    d = hp.desc(B)
+
+    def run_pair(acts):
+        full = hp.select_topk(d, acts, k * B)
+        car = hp.select_topk(d, acts, k * B, carry=True)
+        torch.cuda.synchronize()
+        nnz = int(full.row_ptr[-1])
+        assert nnz == k * B
+        for a, b, name in zip(_sel_tuple(car, nnz), _sel_tuple(full, nnz), ("state", "row_ptr", "col_idx", "vals")):
+            if name == "state":
+                a, b = a[:8], b[:8]
+            assert torch.equal(a, b), name
+
+    carry = hp.carry_state(torch.device("cuda:0"))
+    acts = torch.relu(torch.randn(B, D, device="cuda")).to(dt)
+    run_pair(acts)                                      # 1: no bound yet
+    assert carry[4].item() == 0 and carry[5].item() == 1 and carry[0].item() != 0
+    run_pair(acts)                                      # 2: bound from call 1 -> compact path
+    assert carry[4].item() == 1
+    acts2 = (acts.float() * 1.01).to(dt)                # 3: slightly different batch, still the compact path
+    run_pair(acts2)
+    assert carry[4].item() == 2
+    if dt == torch.bfloat16:                            # heavy ties at tau inside the compact matrix
+        acts3 = (acts2.float() * 16).round().div(16).to(dt)
+        carry[0] = 0
+        run_pair(acts3); run_pair(acts3)
+        assert carry[4].item() == 3
+    served = carry[4].item()
+    run_pair((acts.float() * 0.25).to(dt))              # 4: bound far too high -> fewer than k candidates -> full
+    assert carry[4].item() == served
+    # 5: one row holds more candidates than the compact matrix has columns (1024) -> full passes
+    acts5 = acts.clone()
+    acts5[3] = (torch.rand(D, device="cuda") + 10).to(dt)
+    hp.select_topk(d, acts5, k * B, carry=True)         # refresh the bound on this data (may or may not be compact)
+    served = carry[4].item()
+    run_pair(acts5)
+    assert carry[4].item() == served
+    # 6: fewer positives than k: bound disabled afterwards
+    acts6 = torch.zeros(B, D, device="cuda", dtype=dt)
+    acts6[:, :4] = 1.0
+    full = hp.select_topk(d, acts6, k * B)
+    car = hp.select_topk(d, acts6, k * B, carry=True)
+    assert torch.equal(full.row_ptr, car.row_ptr) and int(car.row_ptr[-1]) == 4 * B
+    assert carry[0].item() == 0

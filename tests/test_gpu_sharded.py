@@ -34,18 +34,21 @@ def _batches(dt, n=3, B=192):
     return out
 
 
-def _train(model, opt, batches):
+def _train(model, opt, batches, fused=False):
     log = []
     for xs, xt in batches:
-        out = model(xs.cuda(), xt.cuda())
-        out["loss"].backward()
-        opt.step(project=True)
-        opt.zero_grad()
+        if fused:                      # what bench.py runs: FusedAdam.train_step, no materialised gradients
+            out = opt.train_step(xs.cuda(), xt.cuda())
+        else:
+            out = model(xs.cuda(), xt.cuda())
+            out["loss"].backward()
+            opt.step(project=True)
+            opt.zero_grad()
         log.append({k: float(v.detach().float()) for k, v in out.items() if v.dim() == 0})
     return log
 
 
-def _worker(rank, world, port, dt_name, unit, ret):
+def _worker(rank, world, port, dt_name, unit, fused, ret):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         torch.cuda.set_device(0)
@@ -55,7 +58,7 @@ def _worker(rank, world, port, dt_name, unit, ret):
         cfg = _cfg(dt, unit)
         m = ShardedMatryoshkaTranscoder(cfg)
         opt = ShardedFusedAdam(m, lr=cfg["lr"], betas=(cfg["beta1"], cfg["beta2"]))
-        log = _train(m, opt, _batches(dt))
+        log = _train(m, opt, _batches(dt), fused)
         sd = {k: v.cpu() for k, v in m.state_dict().items()}
         cnt = m.gathered_dead_counters().cpu()
         if rank == 0:
@@ -69,8 +72,9 @@ def _worker(rank, world, port, dt_name, unit, ret):
         ret[rank] = traceback.format_exc()
 
 
-@pytest.mark.parametrize("dt_name,unit", [("float32", False), ("bfloat16", True)])
-def test_sharded_matches_single_gpu(dt_name, unit, gpu_lib):
+@pytest.mark.parametrize("dt_name,unit,fused", [("float32", False, False), ("bfloat16", True, False),
+                                                ("float32", False, True), ("bfloat16", True, True)])
+def test_sharded_matches_single_gpu(dt_name, unit, fused, gpu_lib):
     from matryoshka_transcoder_amd.training import FusedAdam
     from matryoshka_transcoder_amd.transcoder import MatryoshkaTranscoder
     dt = getattr(torch, dt_name)
@@ -84,7 +88,7 @@ def test_sharded_matches_single_gpu(dt_name, unit, gpu_lib):
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, dt_name, unit, ret)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, dt_name, unit, fused, ret)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:

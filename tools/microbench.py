@@ -62,6 +62,7 @@ def main():
     tests = {
         "encode": lambda: hp.encode(d, xs, W_encT, b_enc),
         "select_topk": lambda: hp.select_topk(d, acts, k * B),
+        "select_topk_carry": lambda: hp.select_topk(d, acts, k * B, carry=True),
         "build_csc": lambda: hp.build_csc(d, sel, None),
         "decode_G4_fwd_only": lambda: hp.decode(d, sel, W_dec, b_dec, xt, None, None, want_g=True, want_dvals=False),
         "decode_G1_fwd_only": lambda: hp1.decode(d1, sel, W_dec, b_dec, xt, None, None, want_g=True, want_dvals=False),
