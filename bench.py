@@ -210,9 +210,12 @@ def main():
             "fused_backward_adam": ("hbm", 2 * D * A * 6 * s + 2 * B * A * s + nnz * 20, 2 * nnz * A * s),
             "backward": ("hbm", 2 * D * A * s + 2 * B * A * s + nnz * 12, 2 * nnz * A * s),
         }
+        # stage -> (launches per step, kernel name in the committed PMC summary) for the stages priced below
+        launches = {"encode": (1, "mtc::encode_bf16_mfma256_kernel"), "decode": (1, "mtc::decode_fwd_kernel<1, 5>"),
+                    "fused_backward_adam": (2, "mtc::fused_grad_adam_kernel<1, 1, 5, 1, 1>")}
         kernels = {}
         for n, t_ms in st.items():
-            entry = {"ms": t_ms}
+            entry = {"ms": t_ms, "launches": launches.get(n, (None, None))[0]}
             if n in algo:
                 kind, q, gather = algo[n]
                 if gather:
@@ -225,9 +228,20 @@ def main():
                     ach = q / (t_ms * 1e-3) / 1e9
                     entry.update(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS)
             kernels[n] = entry
-        dom = max((n for n in kernels if "bound" in kernels[n]), key=lambda n: kernels[n]["ms"])
-        result["roofline"] = {"kernel": dom, **{k2: kernels[dom][k2] for k2 in ("bound", "achieved", "peak", "unit", "frac")},
-                              "traffic": None}
+        # dominant KERNEL = longest single launch (the fused stage is two launches of one kernel template)
+        per_launch = lambda n: kernels[n]["ms"] / (kernels[n]["launches"] or 1)
+        dom = max((n for n in kernels if "bound" in kernels[n]), key=per_launch)
+        # HBM-side bytes per launch of that kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE,
+        # profiles/README.md); only valid for the workload / dtype they were taken on
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "r01e_pmc_traffic.json")
+        if args.workload == "gemma2-2b" and args.dtype == "bf16" and not args.unit_norm and os.path.exists(pmc_path):
+            with open(pmc_path) as f:
+                pmc = json.load(f)["kernels"]
+            traffic = pmc.get(launches.get(dom, (None, ""))[1], {}).get("hbm_bytes_per_launch")
+        result["roofline"] = {"kernel": launches.get(dom, (None, dom))[1] or dom, "stage": dom,
+                              **{k2: kernels[dom][k2] for k2 in ("bound", "achieved", "peak", "unit", "frac")},
+                              "launch_ms": per_launch(dom), "traffic": traffic, "traffic_unit": "bytes/launch"}
         result["stages"] = kernels
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.workload, dtype)

@@ -219,17 +219,44 @@ __global__ __launch_bounds__(256, (NC <= 5 ? 4 : 2)) void grad_rows_kernel(
 }
 
 // ---------------------------------------------------------------- db_dec = sum_b g_b
+// block = 4 waves x 64 lanes: lane owns one 8-column chunk (16-B loads), the waves split the slab's
+// rows (4 rows in flight per lane), LDS folds the 4 waves; partial[slab][A] in fp32
+constexpr int COLSUM_SLABS = 64;
 template <int DT>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(int B, int A, const void* __restrict__ g, int rows_per_slab,
                                                              float* __restrict__ partial) {
-    typedef typename DType<DT>::T T;
-    const int col = blockIdx.x * 256 + threadIdx.x;
+    __shared__ float sm[4][64][8];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int ch = blockIdx.x * 64 + lane;                 // chunk of 8 columns
     const int slab = blockIdx.y;
-    if (col >= A) return;
+    const bool ok = ch < (A >> 3);
     const int r0 = slab * rows_per_slab, r1 = min(B, r0 + rows_per_slab);
-    float s = 0.f;
-    for (int r = r0; r < r1; ++r) s += DType<DT>::ld(reinterpret_cast<const T*>(g) + (size_t)r * A + col);
-    partial[(size_t)slab * A + col] = s;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (ok) {
+        for (int r = r0 + w; r < r1; r += 16) {
+            Raw<DT> q[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (r + 4 * u < r1) q[u] = load_raw<DT>(g, (size_t)(r + 4 * u) * A + (size_t)ch * 8);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (r + 4 * u < r1) {
+                    float v[8];
+                    unpack(q[u], v);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc[k] += v[k];
+                }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sm[w][lane][k] = acc[k];
+    __syncthreads();
+    if (w == 0 && ok) {
+        float o[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = (sm[0][lane][k] + sm[1][lane][k]) + (sm[2][lane][k] + sm[3][lane][k]);
+        store8<MTC_F32>(partial, (size_t)slab * A + (size_t)ch * 8, o);
+    }
 }
 template <int DT>
 __global__ __launch_bounds__(256) void colsum_finish_kernel(int A, int slabs, const float* __restrict__ partial,
@@ -329,20 +356,20 @@ extern "C" int mtc_backward_sparse(const mtc_desc* d, const int32_t* col_ptr, co
     return check_launch("mtc_backward_sparse");
 }
 
-extern "C" size_t mtc_colsum_workspace_bytes(const mtc_desc* d) { return d ? 32 * (size_t)d->A_t * sizeof(float) : 0; }
+extern "C" size_t mtc_colsum_workspace_bytes(const mtc_desc* d) { return d ? COLSUM_SLABS * (size_t)d->A_t * sizeof(float) : 0; }
 
 extern "C" int mtc_colsum(const mtc_desc* d, const void* g, const float* scale, void* workspace, size_t workspace_bytes,
                           void* db_dec, int accumulate, void* stream) {
     if (check_desc(d, "mtc_colsum")) return -1;
     MTC_REQUIRE(g && workspace && db_dec, "mtc_colsum: null pointer");
     MTC_REQUIRE(workspace_bytes >= mtc_colsum_workspace_bytes(d), "mtc_colsum: workspace too small");
-    const int slabs = 32, rows_per = (d->B + slabs - 1) / slabs;
+    const int slabs = COLSUM_SLABS, rows_per = (d->B + slabs - 1) / slabs;
     hipStream_t s = as_stream(stream);
     if (d->dtype == MTC_BF16)
-        hipLaunchKernelGGL(colsum_partial_kernel<MTC_BF16>, dim3((d->A_t + 255) / 256, slabs), dim3(256), 0, s, d->B, d->A_t, g,
+        hipLaunchKernelGGL(colsum_partial_kernel<MTC_BF16>, dim3((d->A_t / 8 + 63) / 64, slabs), dim3(256), 0, s, d->B, d->A_t, g,
                            rows_per, reinterpret_cast<float*>(workspace));
     else
-        hipLaunchKernelGGL(colsum_partial_kernel<MTC_F32>, dim3((d->A_t + 255) / 256, slabs), dim3(256), 0, s, d->B, d->A_t, g,
+        hipLaunchKernelGGL(colsum_partial_kernel<MTC_F32>, dim3((d->A_t / 8 + 63) / 64, slabs), dim3(256), 0, s, d->B, d->A_t, g,
                            rows_per, reinterpret_cast<float*>(workspace));
     if (d->dtype == MTC_BF16)
         hipLaunchKernelGGL(colsum_finish_kernel<MTC_BF16>, dim3((d->A_t + 255) / 256), dim3(256), 0, s, d->A_t, slabs,

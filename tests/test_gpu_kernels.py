@@ -352,3 +352,45 @@ def test_select_carry_is_identical_to_full_select(dt, gpu_lib):
     car = hp.select_topk(d, acts6, k * B, carry=True)
     assert torch.equal(full.row_ptr, car.row_ptr) and int(car.row_ptr[-1]) == 4 * B
     assert carry[0].item() == 0
+
+
+@pytest.mark.parametrize("dt,A", [(torch.bfloat16, 768), (torch.float32, 512), (torch.bfloat16, 2304)])
+def test_fused_backward_adam_equals_backward_then_adam(dt, A, gpu_lib):
+    """The fused per-row {gradient -> [projection] -> Adam} kernels (and d_vals produced by the decoder kernel)
+    against the materialised path:
+    mtc_backward_sparse, then mtc_unitnorm_adam_rows / mtc_adam_flat.  Same arithmetic -> identical bits."""
+    from matryoshka_transcoder_amd.engine import HotPath, adam_hyper
+    torch.manual_seed(11)
+    D, B, k = 1208, 96, 12           # D/8 = 151 features per XCD: not a multiple of 4
+    hp = HotPath(A, A, [200, 1208], dt, False)
+    d = hp.desc(B)
+    dev = "cuda"
+    xs = torch.randn(B, A).to(dt).to(dev); xt = torch.randn(B, A).to(dt).to(dev)
+    W_encT = (torch.randn(D, A) * 0.05).to(dt).to(dev); W_dec = (torch.randn(D, A) * 0.05).to(dt).to(dev)
+    b_enc = (torch.randn(D) * 0.01).to(dt).to(dev); b_dec = torch.zeros(A, dtype=dt, device=dev)
+    acts = hp.encode(d, xs, W_encT, b_enc)
+    sel = hp.select_topk(d, acts, k * B)
+    hp.build_csc(d, sel, None)
+    l1_term = 3e-6
+    x_hat, g, rs, _, d_vals = hp.decode(d, sel, W_dec, b_dec, xt, None, None, want_g=True, want_dvals=True, l1_term=l1_term)
+    h = adam_hyper(3e-4, 0.9, 0.99, 1e-8, 2)
+
+    def fresh():
+        gen = torch.Generator("cpu").manual_seed(3)
+        mk = lambda *s: (torch.randn(*s, generator=gen) * 1e-3).to(dt).to(dev)
+        mv = lambda *s: (torch.rand(*s, generator=gen) * 1e-6).to(dt).to(dev)
+        return dict(Wd=W_dec.clone(), We=W_encT.clone(), be=b_enc.clone(), md=mk(D, A), vd=mv(D, A), me=mk(D, A), ve=mv(D, A),
+                    mb=mk(D), vb=mv(D))
+
+    ref = fresh()
+    dW_dec, dW_encT, db_enc, _ = hp.backward(d, sel, g, d_vals, xs, None)
+    hp.unitnorm_adam(ref["Wd"], dW_dec, ref["md"], ref["vd"], h, write_grad=False)
+    hp.adam_flat(ref["We"], dW_encT, ref["me"], ref["ve"], h)
+    hp.adam_flat(ref["be"], db_enc, ref["mb"], ref["vb"], h)
+    for deferred in (False, True):
+        got = fresh()
+        hp.fused_backward_adam(d, sel, g, None if deferred else d_vals, xs, None, got["Wd"], (got["md"], got["vd"]),
+                               got["We"], (got["me"], got["ve"]), got["be"], (got["mb"], got["vb"]), h, h, h, l1_term=l1_term)
+        torch.cuda.synchronize()
+        for name in ref:
+            assert torch.equal(got[name], ref[name]), (name, deferred, float((got[name].float() - ref[name].float()).abs().max()))
