@@ -206,6 +206,104 @@ __global__ __launch_bounds__(256, 2) void encode_bf16_mfma_kernel(const u16* __r
     }
 }
 
+// ------------------------------------------------------------------------------------------- K1 fp32 MFMA
+// fp32 model dtype (the reference's default, config.py:72): the same 128 x 128 tile, LDS image and
+// staging as the bf16 kernel above with 32 floats per 128-byte LDS row.  v_mfma_f32_16x16x4_f32 is an
+// exact fp32 fma chain.  One ds_read_b128 gives a lane 4 consecutive k of its row; MFMA number c of a
+// group consumes component c, so the four lane groups (lane >> 4) feed k = 16 g + 4 q + c -- a
+// permutation of k that is the same for both operands, which is all a dot product needs.
+constexpr int BK32 = 32;
+__global__ __launch_bounds__(256, 2) void encode_f32_mfma_kernel(const float* __restrict__ X, const float* __restrict__ Wt,
+                                                                 const float* __restrict__ bias, float* __restrict__ acts,
+                                                                 int M, int N, int K, int mt, int nt) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int tm, tn;
+    xcd_tile_coords(blockIdx.x, mt * nt, mt, nt, tm, tn);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wb = wid & 1, wf = wid >> 1;
+    const int row0 = tm * BM, col0 = tn * BN;
+    const int srow = lane >> 3;
+    const float* xsrc[4];
+    const float* wsrc[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int r = (wid * 4 + p) * 8 + srow;
+        const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+        const int xr = min(row0 + r, M - 1), wr = min(col0 + r, N - 1);
+        xsrc[p] = X + (size_t)xr * K + chunk * 4;
+        wsrc[p] = Wt + (size_t)wr * K + chunk * 4;
+    }
+    auto stage = [&](int buf, int kt) {
+        char* base = smem + buf * 2 * TILE_BYTES;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            glds16(xsrc[p] + kt * BK32, base + (wid * 4 + p) * 1024);
+            glds16(wsrc[p] + kt * BK32, base + TILE_BYTES + (wid * 4 + p) * 1024);
+        }
+    };
+    const int fr = lane & 15, fq = lane >> 4;
+    const int swz = (fr >> 1) & 7;
+    int aoff[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) aoff[g] = fr * 128 + (((g * 4 + fq) ^ swz) << 4);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int ktiles = K / BK32;
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < ktiles; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < ktiles) stage(cur ^ 1, kt + 1);
+        const char* xs = smem + cur * 2 * TILE_BYTES + wb * 64 * 128;
+        const char* ws = smem + cur * 2 * TILE_BYTES + TILE_BYTES + wf * 64 * 128;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            f32x4 wfr[4], xfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                wfr[i] = *reinterpret_cast<const f32x4*>(ws + i * 16 * 128 + aoff[g]);
+                xfr[i] = *reinterpret_cast<const f32x4*>(xs + i * 16 * 128 + aoff[g]);
+            }
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wfr[i][c], xfr[j][c], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    // ---- epilogue: lane holds features f = fbase + i*16 + r (r = 0..3) of batch row b = bbase + j*16
+    const int fbase = col0 + wf * 64 + fq * 4;
+    const int bbase = row0 + wb * 64 + fr;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = fbase + i * 16;
+        if (f >= N) continue;
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + f);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int b = bbase + j * 16;
+            if (b >= M) continue;
+            f32x4 v = acc[i][j];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float pre = v[r] + bb[r]; v[r] = pre > 0.f ? pre : 0.f; }
+            *reinterpret_cast<f32x4*>(acts + (size_t)b * N + f) = v;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------- K1 bf16 MFMA, 256x256 tile
 // Large problems (>= 2 tiles per CU): 256 (batch) x 256 (features) x 64 tiles double the FLOP per
 // operand byte of the 128^2 kernel (whose 64 FLOP/B needs ~37 TB/s of L2 at MFMA peak).  One
@@ -467,6 +565,15 @@ extern "C" int mtc_encode_fwd(const mtc_desc* d, const void* x, const void* W_en
     if (check_desc(d, "mtc_encode_fwd")) return -1;
     MTC_REQUIRE(x && W_encT && b_enc && acts, "mtc_encode_fwd: null pointer");
     const int M = d->B, N = d->D, K = d->A_s;
+    if (d->dtype == MTC_F32 && (K % BK32) == 0 && !(getenv("MTC_ENCODE_F32_GENERIC"))) {
+        const int lds = 2 * 2 * TILE_BYTES;
+        hipFuncSetAttribute(reinterpret_cast<const void*>(encode_f32_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        const int mt = (M + BM - 1) / BM, nt = (N + BN - 1) / BN;
+        hipLaunchKernelGGL(encode_f32_mfma_kernel, dim3(mt * nt), dim3(256), lds, as_stream(stream),
+                           reinterpret_cast<const float*>(x), reinterpret_cast<const float*>(W_encT),
+                           reinterpret_cast<const float*>(b_enc), reinterpret_cast<float*>(acts), M, N, K, mt, nt);
+        return check_launch("mtc_encode_fwd");
+    }
     const char* force = getenv("MTC_ENCODE_TILE");
     const int big_tiles = ((M + B2M - 1) / B2M) * ((N + B2N - 1) / B2N);
     if (d->dtype == MTC_BF16 && (K % BK) == 0 && ((big_tiles >= 512 && !(force && force[0] == '1')) || (force && force[0] == '2'))) {
