@@ -18,6 +18,8 @@ Step (RCCL through torch.distributed; every exchange is a real data dependency o
      x_hat / per-prefix SSE / g for B/world rows -> all-gather of x_hat and g (model dtype);
   4. backward and Adam are local to the shard (no gradient all-reduce); db_dec is identical
      everywhere because g is.
+  5. while dead features exist: the auxiliary loss over shards (`_run_aux`): all-gather of per-row
+     candidates, all-gather of tie counts, fp32 all-reduce of the partial aux reconstruction.
 `state_dict()` gathers to the reference's layout; `load_state_dict()` scatters from it.
 """
 from __future__ import annotations
@@ -200,10 +202,92 @@ class ShardedMatryoshkaTranscoder(MatryoshkaTranscoder):
         return sel
 
     # ------------------------------------------------------------------ step 3: decode + losses
+    def _aux_may_be_active(self) -> bool:
+        """Same host-side bound as the single-GPU model, on the GLOBAL maximum of the dead counters so that
+        every rank takes the same branch (and issues the same collectives) on the same step."""
+        if self._dead_check_in > 0:
+            return False
+        n_dead_at = float(self.config["n_batches_to_dead"])
+        mx_t = self._cnt.max().reshape(1).clone()
+        self.comm.all_reduce(mx_t, op=dist.ReduceOp.MAX)
+        mx = float(mx_t.item())
+        if mx >= n_dead_at:
+            return True
+        import math
+        self._dead_check_in = max(int(math.ceil(n_dead_at - mx)) - 1, 0)
+        return False
+
+    def _run_aux(self, hp, d, acts, sel, W_dec, x_target, x_hat, g, need_grad, l1_term):
+        """Auxiliary dead-feature loss (sae.py:318-347) over a feature-sharded dictionary.  The per-row
+        top-k_aux over ALL dead features is found from an all-gather of every rank's local per-row
+        candidates (k_aux values per row), ties at a row's threshold are granted in (rank, feature) order
+        from an all-gather of the tie counts, the partial reconstructions are summed with an all-reduce
+        (fp32), and the residual / loss / gradient part runs replicated.  The selection and the sums use
+        the libmtc kernels; the candidate merge is torch.topk on [B, world * k_aux] -- this path runs only
+        while dead features exist."""
+        cfg, comm = self.config, self.comm
+        lib, s, dev = hp.lib, _stream(), acts.device
+        B, A_t, Dl = d.B, hp.A_t, hp.D
+        k_aux = int(cfg["top_k_aux"])
+        n_to_dead = float(cfg["n_batches_to_dead"])
+        penalty = float(cfg["aux_penalty"])
+        # local candidates: the k_aux largest activations of every row among the local dead columns
+        dead_mask = self._cnt >= n_to_dead
+        masked = torch.where(dead_mask.unsqueeze(0), acts, torch.zeros((), dtype=acts.dtype, device=dev))
+        kk = min(k_aux, Dl)
+        cand = torch.zeros(B, k_aux, dtype=acts.dtype, device=dev)
+        cand[:, :kk] = torch.topk(masked, kk, dim=1).values
+        allc = comm.all_gather(cand).permute(1, 0, 2).reshape(B, -1)            # [B, world * k_aux]
+        top = torch.topk(allc.float(), k_aux, dim=1).values
+        tau = top[:, -1].clamp_min(0.0)                                          # 0: fewer than k_aux positives -> take them all
+        n_gt_glob = (allc.float() > tau.unsqueeze(1)).sum(1)
+        quota = torch.where(tau > 0, k_aux - n_gt_glob, torch.zeros_like(n_gt_glob))
+        mf = masked.float()
+        gt_loc = (mf > tau.unsqueeze(1)).sum(1)
+        eq_loc = ((mf == tau.unsqueeze(1)) & (tau.unsqueeze(1) > 0)).sum(1)
+        all_eq = comm.all_gather(eq_loc.to(torch.int32))                         # [world, B]
+        before = all_eq[:comm.rank].sum(0) if comm.rank > 0 else torch.zeros_like(eq_loc)
+        take = torch.minimum((quota - before).clamp_min(0), eq_loc).to(torch.int32)
+        row_cnt = (gt_loc + take).to(torch.int32).contiguous()
+        row_tau = tau.contiguous().view(torch.int32)
+        # CSR of the local aux entries (ascending local feature inside a row), same kernels as the single-GPU path
+        dead_idx = torch.empty(Dl, dtype=torch.int32, device=dev)
+        n_dead = torch.empty(1, dtype=torch.int32, device=dev)
+        check(lib.mtc_aux_dead_list(C.byref(d), _p(self._cnt), n_to_dead, _p(dead_idx), _p(n_dead), s), "mtc_aux_dead_list")
+        st = torch.empty(16, dtype=torch.int32, device=dev)
+        zeros = torch.zeros(B, dtype=torch.int32, device=dev)
+        row_ptr = torch.empty(B + 1, dtype=torch.int32, device=dev)
+        tie_take = torch.empty(B, dtype=torch.int32, device=dev)
+        check(lib.mtc_select_init(_p(st), 0, s), "mtc_select_init")
+        check(lib.mtc_select_offsets(C.byref(d), _p(row_cnt), _p(zeros), None, _p(st), _p(row_ptr), _p(tie_take), s),
+              "mtc_select_offsets")
+        cap = max(B * min(k_aux, Dl), 1)
+        col_idx = torch.empty(cap, dtype=torch.int32, device=dev)
+        vals = torch.empty(cap, dtype=self.dtype, device=dev)
+        check(lib.mtc_aux_fill(C.byref(d), _p(acts), _p(dead_idx), _p(n_dead), _p(row_tau), _p(take.contiguous()), _p(row_ptr),
+                               _p(col_idx), _p(vals), s), "mtc_aux_fill")
+        asel = Selection(st, row_ptr, col_idx, vals)
+        # partial aux reconstruction of the local entries (bias-free, fp32) -> all-reduce
+        d1 = _lib.make_desc(B, hp.A_s, hp.A_t, Dl, [Dl], hp.code, hp.unit_norm)
+        part = torch.empty(B, A_t, dtype=torch.float32, device=dev)
+        dummy = torch.empty(8, dtype=self.dtype, device=dev)
+        check(lib.mtc_decode_partial(C.byref(d1), _p(row_ptr), _p(col_idx), _p(vals), _p(W_dec), B, _p(part), _p(dummy), None, s),
+              "mtc_decode_partial")
+        comm.all_reduce(part)
+        # replicated: e = round(x_aux) - (x_t - x_hat); aux = penalty * mean(e^2); g_aux; g += g_aux * std_row
+        e = part.to(self.dtype).float() - (x_target.float() - x_hat.float())
+        aux_rows = (e * e).sum(1).contiguous()
+        ga32 = e * (2.0 * penalty / (B * A_t))
+        g_aux = ga32.to(self.dtype).contiguous()
+        std_row = self.x_std.reshape(-1, 1).float() if hp.unit_norm else 1.0
+        g.copy_((g.float() + ga32 * std_row).to(self.dtype))
+        d_aux = None
+        if need_grad:
+            d_aux = hp.decode_bwd_vals(d, asel, W_dec, g_aux, 0.0)
+            hp.build_csc(d, asel, None)
+        return dict(sel=asel, g_aux=g_aux, d_vals=d_aux), aux_rows
+
     def _decode_and_losses(self, hp, d, sel, acts, W_dec, b_dec, x_target, mean, std, need_grad, aux_active):
-        if aux_active:
-            raise _lib.MtcError("dead features exist, but the auxiliary loss is not built for the feature-sharded "
-                                "model yet (single-GPU MatryoshkaTranscoder has it)")
         cfg = self.config
         lib, s, dev = hp.lib, _stream(), x_target.device
         B, A_t, G, W, rank = d.B, hp.A_t, d.G, self.comm.world, self.comm.rank
@@ -236,10 +320,15 @@ class ShardedMatryoshkaTranscoder(MatryoshkaTranscoder):
         g = both[:, 1].reshape(B, A_t).contiguous()
         row_stats = self.comm.all_gather(stats_l).permute(1, 0, 2).reshape(G + 4, B).contiguous()
         l1_term = float(cfg["l1_coeff"]) / (B * self.total_dict_size)
-        d_vals = hp.decode_bwd_vals(d, sel, W_dec, g, l1_term) if need_grad and not getattr(self, "_defer_dvals", False) else None
+        x_hat = x_hat.contiguous()
+        aux, aux_rows = None, None
+        if aux_active:
+            aux, aux_rows = self._run_aux(hp, d, acts, sel, W_dec, x_target, x_hat, g, need_grad, l1_term)
+        defer = getattr(self, "_defer_dvals", False) and not aux_active
+        d_vals = hp.decode_bwd_vals(d, sel, W_dec, g, l1_term) if need_grad and not defer else None
         scalars = hp.reduce_scalars(d, row_stats, sel, self.total_dict_size, float(cfg["l1_coeff"]),
-                                    float(cfg["aux_penalty"]), nnz_abs_override=nnz_abs)
-        return x_hat.contiguous(), g, d_vals, row_stats, scalars, None
+                                    float(cfg["aux_penalty"]), aux_rows=aux_rows, nnz_abs_override=nnz_abs)
+        return x_hat, g, d_vals, row_stats, scalars, aux
 
     # ------------------------------------------------------------------ checkpoints in the reference layout
     def _gather_features(self, local: torch.Tensor, dim: int) -> torch.Tensor:

@@ -20,9 +20,11 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _cfg(dt, unit):
+def _cfg(dt, unit, aux=False):
+    # aux=True: features that stay silent for 2 batches count as dead, so the auxiliary loss (sae.py:318-347)
+    # is active from the third step on
     return dict(seed=49, prefix_sizes=[256, 768, 1792, 4096], act_size=256, top_k=32, top_k_aux=64,
-                aux_penalty=1 / 32, n_batches_to_dead=20, l1_coeff=1e-3, dtype=dt, device="cuda:0",
+                aux_penalty=1 / 32, n_batches_to_dead=2 if aux else 20, l1_coeff=1e-3, dtype=dt, device="cuda:0",
                 input_unit_norm=unit, lr=3e-4, beta1=0.9, beta2=0.99)
 
 
@@ -48,17 +50,17 @@ def _train(model, opt, batches, fused=False):
     return log
 
 
-def _worker(rank, world, port, dt_name, unit, fused, ret):
+def _worker(rank, world, port, dt_name, unit, fused, aux, ret):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         torch.cuda.set_device(0)
         dist.init_process_group("gloo", rank=rank, world_size=world)
         from matryoshka_transcoder_amd.sharded import ShardedFusedAdam, ShardedMatryoshkaTranscoder
         dt = getattr(torch, dt_name)
-        cfg = _cfg(dt, unit)
+        cfg = _cfg(dt, unit, aux)
         m = ShardedMatryoshkaTranscoder(cfg)
         opt = ShardedFusedAdam(m, lr=cfg["lr"], betas=(cfg["beta1"], cfg["beta2"]))
-        log = _train(m, opt, _batches(dt), fused)
+        log = _train(m, opt, _batches(dt, n=6 if aux else 3), fused)
         sd = {k: v.cpu() for k, v in m.state_dict().items()}
         cnt = m.gathered_dead_counters().cpu()
         if rank == 0:
@@ -72,15 +74,19 @@ def _worker(rank, world, port, dt_name, unit, fused, ret):
         ret[rank] = traceback.format_exc()
 
 
-@pytest.mark.parametrize("dt_name,unit,fused", [("float32", False, False), ("bfloat16", True, False),
-                                                ("float32", False, True), ("bfloat16", True, True)])
-def test_sharded_matches_single_gpu(dt_name, unit, fused, gpu_lib):
+@pytest.mark.parametrize("dt_name,unit,fused,aux", [("float32", False, False, False), ("bfloat16", True, False, False),
+                                                    ("float32", False, True, False), ("bfloat16", True, True, False),
+                                                    ("float32", False, True, True), ("float32", True, False, True),
+                                                    ("bfloat16", True, True, True)])
+def test_sharded_matches_single_gpu(dt_name, unit, fused, aux, gpu_lib):
     from matryoshka_transcoder_amd.training import FusedAdam
     from matryoshka_transcoder_amd.transcoder import MatryoshkaTranscoder
     dt = getattr(torch, dt_name)
-    cfg = _cfg(dt, unit)
+    cfg = _cfg(dt, unit, aux)
     ref = MatryoshkaTranscoder(cfg)
-    ref_log = _train(ref, FusedAdam(ref, lr=cfg["lr"], betas=(cfg["beta1"], cfg["beta2"])), _batches(dt))
+    ref_log = _train(ref, FusedAdam(ref, lr=cfg["lr"], betas=(cfg["beta1"], cfg["beta2"])), _batches(dt, n=6 if aux else 3))
+    if aux:
+        assert ref_log[-1]["aux_loss"] > 0, "the test configuration must make the auxiliary loss active"
     ref_sd = {k: v.cpu() for k, v in ref.state_dict().items()}
     ref_cnt = ref.num_batches_not_active.cpu()
     torch.cuda.synchronize()
@@ -88,7 +94,7 @@ def test_sharded_matches_single_gpu(dt_name, unit, fused, gpu_lib):
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, dt_name, unit, fused, ret)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, dt_name, unit, fused, aux, ret)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
