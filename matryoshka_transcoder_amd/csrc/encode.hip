@@ -84,8 +84,8 @@ __device__ __forceinline__ void xcd_tile_coords(int bid, int nblk, int mt, int n
     // blocks b, b+8, ... share an XCD: give each XCD a contiguous run of logical ids (bijective form)
     const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
     const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    // logical ids walk 8-wide groups of batch tiles under each feature tile
-    constexpr int GROUP = 8;
+    // logical ids walk GROUP-wide groups of batch tiles under each feature tile
+    constexpr int GROUP = 4;     // measured at config #2: 4 and 2 beat 8 and 16 by 3-5 % (smaller per-XCD working set per K step)
     const int per_group = GROUP * nt;
     const int g = lid / per_group;
     const int first_m = g * GROUP;
