@@ -368,13 +368,47 @@ class ShardedMatryoshkaTranscoder(MatryoshkaTranscoder):
     def encode(self, x_source):
         """Dense [.., D] features in GLOBAL feature order (collective)."""
         shape = x_source.shape
-        local = super().encode(x_source)
+        global_indices = self.prefix_indices
+        self.prefix_indices = [0] + list(self.local_prefix_sizes)      # the base class cuts at the active prefix: local coordinates
+        try:
+            local = super().encode(x_source)
+        finally:
+            self.prefix_indices = global_indices
         full = self._gather_features(local.reshape(-1, local.shape[-1]), 1)
         return full.reshape(shape[:-1] + (self.total_dict_size,))
 
     def decode(self, acts_topk):
-        raise _lib.MtcError("decode() of a dense global feature tensor is not built for the sharded model; gather the "
-                            "state_dict into a single-GPU MatryoshkaTranscoder for inference")
+        """sae.py:389-406 for a dense [N, D] tensor in GLOBAL feature order (what encode() returns; collective):
+        every rank decodes its own columns into a bias-free fp32 partial sum, the partials are all-reduced,
+        bias and de-normalisation follow replicated."""
+        if not hasattr(self, "x_mean"):
+            raise AttributeError("decode() needs the statistics of a previous encode()")
+        if acts_topk.dim() != 2 or acts_topk.shape[1] < self.prefix_indices[self.active_prefixes]:
+            raise _lib.MtcError(f"decode() expects [N, >= {self.prefix_indices[self.active_prefixes]}] features in global order, "
+                                f"got {tuple(acts_topk.shape)}")
+        hp0 = self.hot_path()
+        lib, s, dev = hp0.lib, _stream(), acts_topk.device
+        N = acts_topk.shape[0]
+        local_max = ([0] + list(self.local_prefix_sizes))[self.active_prefixes]
+        idx = self.layout.global_index(self.comm.rank)[:local_max].to(dev)
+        dense = acts_topk.index_select(1, idx).to(self.dtype).contiguous()
+        sub = HotPath(self.source_act_size, self.target_act_size, [local_max], self.dtype, False)
+        d = sub.desc(N)
+        nan = torch.full((1,), float("nan"), dtype=self.dtype, device=dev)      # "non-zero" select mode
+        sel = sub.select_threshold(d, dense, nan)
+        part = torch.empty(N, sub.A_t, dtype=torch.float32, device=dev)
+        dummy = torch.empty(8, dtype=self.dtype, device=dev)
+        check(lib.mtc_decode_partial(C.byref(d), _p(sel.row_ptr), _p(sel.col_idx), _p(sel.vals),
+                                     _p(self.W_dec.data[:local_max].contiguous()), N, _p(part), _p(dummy), None, s),
+              "mtc_decode_partial")
+        self.comm.all_reduce(part)
+        out = (part + self.b_dec.data.float()).to(self.dtype)
+        if bool(self.config.get("input_unit_norm", False)):
+            if self.x_mean is None or self.x_mean.numel() != N:
+                raise RuntimeError(f"decode(): statistics of the last encode() cover "
+                                   f"{0 if self.x_mean is None else self.x_mean.numel()} rows but {N} rows were given")
+            out = out * self.x_std.reshape(N, 1) + self.x_mean.reshape(N, 1)      # each op rounds to the model dtype
+        return out
 
 
 class ShardedFusedAdam(FusedAdam):

@@ -63,7 +63,14 @@ def _worker(rank, world, port, dt_name, unit, fused, aux, ret):
         log = _train(m, opt, _batches(dt, n=6 if aux else 3), fused)
         sd = {k: v.cpu() for k, v in m.state_dict().items()}
         cnt = m.gathered_dead_counters().cpu()
+        m.eval()
+        with torch.no_grad():
+            xe = _batches(dt, n=1, B=40)[0][0].cuda()
+            feats = m.encode(xe)
+            recon = m.decode(feats)
+        m.train()
         if rank == 0:
+            ret["feats"], ret["recon"] = feats.cpu(), recon.cpu()
             ret["log"] = log
             ret["sd"] = sd
             ret["cnt"] = cnt
@@ -89,6 +96,12 @@ def test_sharded_matches_single_gpu(dt_name, unit, fused, aux, gpu_lib):
         assert ref_log[-1]["aux_loss"] > 0, "the test configuration must make the auxiliary loss active"
     ref_sd = {k: v.cpu() for k, v in ref.state_dict().items()}
     ref_cnt = ref.num_batches_not_active.cpu()
+    ref.eval()
+    with torch.no_grad():
+        xe = _batches(dt, n=1, B=40)[0][0].cuda()
+        ref_feats = ref.encode(xe)
+        ref_recon = ref.decode(ref_feats).cpu()
+        ref_feats = ref_feats.cpu()
     torch.cuda.synchronize()
 
     ctx = mp.get_context("spawn")
@@ -107,6 +120,14 @@ def test_sharded_matches_single_gpu(dt_name, unit, fused, aux, gpu_lib):
         for k in b:
             assert abs(a[k] - b[k]) <= rtol * abs(b[k]) + 1e-7, (k, a[k], b[k])
     assert torch.equal(ret["cnt"], ref_cnt) or not f32
+    # eval-mode encode() / decode() of the sharded model (collectives) against the single-GPU model: the
+    # weights differ by the training tolerance above, so features are compared where both fire
+    assert ret["feats"].shape == ref_feats.shape and ret["recon"].shape == ref_recon.shape
+    both = (ret["feats"] > 0) & (ref_feats > 0)
+    assert both.sum() >= 0.9 * (ref_feats > 0).sum()
+    assert torch.allclose(ret["feats"][both].float(), ref_feats[both].float(), rtol=5e-2, atol=1e-3)
+    err = (ret["recon"].float() - ref_recon.float()).abs().max()
+    assert err <= (2e-3 if f32 else 1e-1) * max(1.0, float(ref_recon.float().abs().max())), float(err)
     for k, v in ref_sd.items():
         got = ret["sd"][k]
         assert got.shape == v.shape
