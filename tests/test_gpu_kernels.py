@@ -394,3 +394,24 @@ def test_fused_backward_adam_equals_backward_then_adam(dt, A, gpu_lib):
         torch.cuda.synchronize()
         for name in ref:
             assert torch.equal(got[name], ref[name]), (name, deferred, float((got[name].float() - ref[name].float()).abs().max()))
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("unit", [False, True])
+def test_ragged_shapes(dt, unit, gpu_lib):
+    """Nothing is a multiple of a tile: B = 37 rows (odd: partial wave-per-row workgroups), A = 264 (multiple of 8
+    only -> generic encoder, a half-filled last register chunk in the row gathers), D = 1208 with a tiny first
+    prefix group, k = 5."""
+    cfg = dict(seed=49, prefix_sizes=[8, 200, 1208], act_size=264, top_k=5, top_k_aux=16,
+               aux_penalty=1 / 32, n_batches_to_dead=20, l1_coeff=1e-3, dtype=dt, device="cpu",
+               input_unit_norm=unit, lr=3e-4, beta1=0.9, beta2=0.99)
+    B = 37
+    params = R.init_params(cfg)
+    params["b_enc"] = (0.01 * torch.randn(1208, generator=torch.Generator().manual_seed(3))).to(dt)
+    g = torch.Generator("cpu").manual_seed(77)
+    xs = torch.randn(B, 264, generator=g).to(dt)
+    xt = torch.randn(B, 264, generator=g).to(dt)
+    hp = _hot(cfg)
+    cnt = torch.zeros(1208)
+    res = run_forward(hp, cfg, params, cnt, xs, xt)
+    check_against_oracle(cfg, params, cnt, xs, xt, res, hp)
