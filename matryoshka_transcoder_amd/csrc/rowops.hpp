@@ -142,6 +142,15 @@ __device__ __forceinline__ void load_row(rsrc_t rs, uint32_t row_bytes, int j, c
 #pragma unroll
     for (int c = 0; c < NC; ++c) r[c] = load_raw_at<DT>(rs, row_off, co[c]);
 }
+// same, with every lane pushed out of range when `oob` = 0x80000000: a request that is not needed (pipeline
+// refills past the end of a run) then returns zeros without touching memory
+template <int DT, int NC>
+__device__ __forceinline__ void load_row_masked(rsrc_t rs, uint32_t row_bytes, int j, const uint32_t (&co)[NC], uint32_t oob,
+                                                Raw<DT> (&r)[NC]) {
+    const uint32_t row_off = (uint32_t)j * row_bytes;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) r[c] = load_raw_at<DT>(rs, row_off, co[c] | oob);
+}
 template <int DT, int NC, int P>
 __device__ __forceinline__ void accumulate_run_u(const RowCtx<DT, NC>& rc, const void* __restrict__ W, int A,
                                                  int my_col, float my_val, int i0_, int n_, float (&acc)[NC][8]) {
@@ -154,16 +163,18 @@ __device__ __forceinline__ void accumulate_run_u(const RowCtx<DT, NC>& rc, const
     const rsrc_t Wb = make_rsrc(W);
     Raw<DT> r[P][NC];
 #pragma unroll
-    for (int u = 0; u < P; ++u)      // a run shorter than P re-requests its last row (cache hit, coefficient 0 below)
-        load_row<DT, NC>(Wb, row_bytes, __builtin_amdgcn_readlane(my_col, min(i0 + u, last)), co, r[u]);
+    for (int u = 0; u < P; ++u)      // a run shorter than P: the surplus requests are pushed out of range (zeros, no traffic)
+        load_row_masked<DT, NC>(Wb, row_bytes, __builtin_amdgcn_readlane(my_col, min(i0 + u, last)), co,
+                                i0 + u <= last ? 0u : 0x80000000u, r[u]);
     for (int i = i0; i < end; i += P) {
 #pragma unroll
         for (int u = 0; u < P; ++u) {
             const int cur = i + u;
             const float a = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_val), min(cur, last)));
             fma_row<DT, NC>(r[u], cur < end ? a : 0.f, acc);
-            // the refills past the end of the run re-request its last row (cache hits, never consumed)
-            load_row<DT, NC>(Wb, row_bytes, __builtin_amdgcn_readlane(my_col, min(cur + P, last)), co, r[u]);
+            // refills past the end of the run are pushed out of range: unconditional instruction, no memory request
+            load_row_masked<DT, NC>(Wb, row_bytes, __builtin_amdgcn_readlane(my_col, min(cur + P, last)), co,
+                                    cur + P <= last ? 0u : 0x80000000u, r[u]);
         }
     }
 }
@@ -262,8 +273,9 @@ __device__ __forceinline__ void accumulate_dot_run(const RowCtx<DT, NC>& rc, con
         for (int h = 0; h < 4; h += 2) {
             Raw<DT> r[2][NC];
 #pragma unroll
-            for (int u = 0; u < 2; ++u)      // entries past the end re-request the last row (coefficient 0, result unused)
-                load_row<DT, NC>(rs, row_bytes, __builtin_amdgcn_readlane(my_row, min(i + h + u, last)), co, r[u]);
+            for (int u = 0; u < 2; ++u)      // entries past the end: out-of-range request (zeros, no traffic; coefficient 0, result unused)
+                load_row_masked<DT, NC>(rs, row_bytes, __builtin_amdgcn_readlane(my_row, min(i + h + u, last)), co,
+                                        i + h + u <= last ? 0u : 0x80000000u, r[u]);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int cur = i + h + u;
