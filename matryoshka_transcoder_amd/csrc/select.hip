@@ -497,12 +497,20 @@ __global__ __launch_bounds__(256) void select_candidates_kernel(const void* __re
             if (b1) { pos += 2u * mbcnt64(b1); tot += 2u * (uint32_t)__popcll(b1); }
             if (b2) { pos += 4u * mbcnt64(b2); tot += 4u * (uint32_t)__popcll(b2); }
             if (b3) { pos += 8u * mbcnt64(b3); tot += 8u * (uint32_t)__popcll(b3); }
+            // one candidate per lane per round (a lane rarely holds two): 8 predicated store blocks, one per
+            // element position, cost ~10x more instructions than this loop
+            uint32_t mm = m;
+            while (__ballot(mm != 0)) {
+                if (mm) {
+                    const int i = __ffs(mm) - 1;
+                    float val = v[0];
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
-                if (m & (1u << i)) {
-                    if (pos < (uint32_t)C) { DType<DT>::st(vout + pos, v[i]); cout[pos] = c * 8 + i; }
+                    for (int q = 1; q < 8; ++q) val = i == q ? v[q] : val;
+                    if (pos < (uint32_t)C) { DType<DT>::st(vout + pos, val); cout[pos] = c * 8 + i; }
                     ++pos;
+                    mm &= mm - 1;
                 }
+            }
             out += tot;
         }
     }
