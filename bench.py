@@ -132,6 +132,7 @@ def main():
     ap.add_argument("--workload", default="gemma2-2b", choices=list(WORKLOADS))
     ap.add_argument("--unit-norm", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sharded", action="store_true", help="use the feature-sharded classes even on one GPU (overhead check)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -140,13 +141,15 @@ def main():
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
-    if world > 1:
+    if world > 1 or args.sharded:
         import torch.distributed as dist
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=torch.device(device))
 
     cfg, B = make_cfg(args.workload, dtype, device, args.unit_norm)
     A, D, k = cfg["act_size"], cfg["prefix_sizes"][-1], cfg["top_k"]
-    if world > 1:
+    if world > 1 or args.sharded:
         from matryoshka_transcoder_amd.sharded import ShardedMatryoshkaTranscoder, ShardedFusedAdam
         tc = ShardedMatryoshkaTranscoder(cfg)
         opt = ShardedFusedAdam(tc, lr=cfg["lr"], betas=(cfg["beta1"], cfg["beta2"]))
@@ -195,7 +198,7 @@ def main():
                    "global_batch": B, "parallelism": "single GPU" if world == 1 else f"dictionary sharded x{world}",
                    "final_loss": float(out["loss"].detach().float()), "final_l0": float(out["l0_norm"].detach())},
     }
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.sharded:
         st = stage_times(tc, opt, pool)
         s = 2 if dtype == torch.bfloat16 else 4
         nnz = k * B
@@ -247,7 +250,7 @@ def main():
             result["cpu_baseline"] = cpu_baseline(args.workload, dtype)
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if world > 1 or args.sharded:
         import torch.distributed as dist
         dist.destroy_process_group()
 

@@ -129,6 +129,23 @@ int mtc_select_global_topk_carry(const mtc_desc* d, const void* acts, uint32_t k
                                  mtc_select_state* st, int32_t* row_ptr, int32_t* col_idx,
                                  void* vals, void* stream);
 
+/* Helpers of the feature-sharded caller (no counterpart in the single-process reference; each replaces a
+ * handful of tiny tensor ops between two collectives):
+ *   mtc_select_offsets_sharded : mtc_select_offsets with the tie order of a sharded dictionary -- ties are
+ *       granted in (row, shard, feature) order from all_eq [world][B], the all-gathered per-row tie counts;
+ *   mtc_select_pack_minmax     : out2 = {min selected bits, -nnz} (int64) for ONE all-reduce(MIN);
+ *   mtc_threshold_ema_global   : a5 from that reduced pair (skipped when nothing was selected anywhere);
+ *   mtc_shard_nnz_abs          : out2 = {nnz of this shard, sum |a| of its entries} for one all-reduce(SUM)
+ *       that feeds mtc_reduce_scalars(nnz_abs_override). */
+int mtc_select_offsets_sharded(const mtc_desc* d, const uint32_t* row_gt, const uint32_t* all_eq,
+                               int32_t world, int32_t rank, mtc_select_state* st, int32_t* row_ptr,
+                               uint32_t* tie_take, void* stream);
+int mtc_select_pack_minmax(const mtc_select_state* st, int64_t* out2, void* stream);
+int mtc_threshold_ema_global(const mtc_desc* d, const int64_t* minmax2, void* threshold, float lr,
+                             void* stream);
+int mtc_shard_nnz_abs(const mtc_desc* d, const float* abs_rows, const mtc_select_state* st,
+                      float* out2, void* stream);
+
 /* a5  update_threshold (sae.py:349-361): threshold <- (1-lr)*threshold + lr*min_selected, evaluated
  * in the buffer dtype, skipped when nothing was selected. */
 int mtc_threshold_ema(const mtc_desc* d, const mtc_select_state* st, void* threshold, float lr,

@@ -551,6 +551,89 @@ __global__ __launch_bounds__(1024) void select_carry_decide_kernel(uint32_t* car
     }
 }
 
+// ---------------------------------------------------------------- helpers of the feature-sharded caller
+// offsets with the tie order of a sharded dictionary: ties are granted in (row, shard, feature) order, so the
+// ties that precede this shard's row r are all ties of earlier rows (every shard) plus those of earlier shards in
+// row r.  all_eq [world][B] = the all-gathered per-row tie counts; the quota in st is the global one.
+__global__ __launch_bounds__(1024) void select_offsets_sharded_kernel(int B, const uint32_t* __restrict__ row_gt,
+                                                                      const uint32_t* __restrict__ all_eq, int world, int rank,
+                                                                      mtc_select_state* st, int32_t* __restrict__ row_ptr,
+                                                                      uint32_t* __restrict__ tie_take) {
+    __shared__ uint32_t sm[16];
+    const int t = threadIdx.x;
+    const int per = (B + 1023) / 1024;
+    const int r0 = t * per, r1 = min(B, r0 + per);
+    const uint32_t quota = st->n_tie_take;
+    uint32_t my_eq = 0;
+    for (int r = r0; r < r1; ++r)
+        for (int w = 0; w < world; ++w) my_eq += all_eq[(size_t)w * B + r];
+    uint32_t tot;
+    uint32_t run = block_excl_scan_1024(my_eq, sm, &tot);
+    uint32_t my_nnz = 0;
+    for (int r = r0; r < r1; ++r) {
+        uint32_t row_tot = 0, earlier = 0;
+        for (int w = 0; w < world; ++w) {
+            const uint32_t e = all_eq[(size_t)w * B + r];
+            row_tot += e;
+            if (w < rank) earlier += e;
+        }
+        const uint32_t mine = all_eq[(size_t)rank * B + r];
+        const uint32_t before = run + earlier;
+        const uint32_t take = before >= quota ? 0u : min(mine, quota - before);
+        tie_take[r] = take;
+        my_nnz += row_gt[r] + take;
+        run += row_tot;
+    }
+    uint32_t nnz_total;
+    uint32_t base = block_excl_scan_1024(my_nnz, sm, &nnz_total);
+    for (int r = r0; r < r1; ++r) {
+        row_ptr[r] = (int32_t)base;
+        base += row_gt[r] + tie_take[r];
+    }
+    if (t == 0) {
+        row_ptr[B] = (int32_t)nnz_total;
+        st->nnz = nnz_total;
+        if (quota > 0) st->min_sel_bits = min(st->min_sel_bits, st->tau_bits);
+    }
+}
+
+// {min selected bits, -nnz} as int64 for ONE all-reduce(MIN) over the shards, and the EMA from its result
+__global__ void select_pack_minmax_kernel(const mtc_select_state* __restrict__ st, long long* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    out[0] = (long long)st->min_sel_bits;
+    out[1] = -(long long)st->nnz;
+}
+template <int DT>
+__global__ void threshold_ema_global_kernel(const long long* __restrict__ glob, void* threshold, float lr) {
+    typedef DType<DT> D_;
+    typedef typename D_::T T;
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (glob[1] == 0 || glob[0] >= 0xffffffffll) return;               // nothing selected anywhere
+    T* p = reinterpret_cast<T*>(threshold);
+    const float thr = D_::ld(p);
+    const float mn = __uint_as_float((uint32_t)glob[0]);
+    const float a = D_::rnd((float)(1.0 - (double)lr) * thr);
+    const float b = D_::rnd(lr * mn);
+    D_::st(p, D_::rnd(a + b));
+}
+// out[0] = nnz of this shard, out[1] = sum |a| of its selected entries (one workgroup; feeds one all-reduce(SUM))
+__global__ __launch_bounds__(1024) void nnz_abs_kernel(int B, const float* __restrict__ abs_rows, const mtc_select_state* __restrict__ st,
+                                                       float* __restrict__ out) {
+    __shared__ float sm[16];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    float s = 0.f;
+    for (int r = t; r < B; r += 1024) s += abs_rows[r];
+    s = wave_sum(s);
+    if (lane == 0) sm[w] = s;
+    __syncthreads();
+    if (t == 0) {
+        float tot = 0.f;
+        for (int i = 0; i < 16; ++i) tot += sm[i];
+        out[0] = (float)st->nnz;
+        out[1] = tot;
+    }
+}
+
 template <int DT>
 __global__ void threshold_ema_kernel(const mtc_select_state* __restrict__ st, void* threshold, float lr) {
     typedef DType<DT> D_;
@@ -806,6 +889,38 @@ extern "C" int mtc_select_global_topk_carry(const mtc_desc* d, const void* acts,
     if ((rc = offsets_impl(d, row_gt, row_eq, nullptr, st, row_ptr, tie_take, carry, stream))) return rc;
     if ((rc = fill_impl(d, C, cand_vals, st, nullptr, row_ptr, tie_take, col_idx, vals, cand_cols, flag, 1, stream))) return rc;
     return fill_impl(d, d->D, acts, st, nullptr, row_ptr, tie_take, col_idx, vals, nullptr, flag, 0, stream);
+}
+
+extern "C" int mtc_select_offsets_sharded(const mtc_desc* d, const uint32_t* row_gt, const uint32_t* all_eq, int32_t world,
+                                          int32_t rank, mtc_select_state* st, int32_t* row_ptr, uint32_t* tie_take,
+                                          void* stream) {
+    if (check_desc(d, "mtc_select_offsets_sharded")) return -1;
+    MTC_REQUIRE(row_gt && all_eq && st && row_ptr && tie_take, "mtc_select_offsets_sharded: null pointer");
+    MTC_REQUIRE(world >= 1 && rank >= 0 && rank < world, "mtc_select_offsets_sharded: bad rank %d of %d", rank, world);
+    hipLaunchKernelGGL(select_offsets_sharded_kernel, dim3(1), dim3(1024), 0, as_stream(stream), d->B, row_gt, all_eq, world,
+                       rank, st, row_ptr, tie_take);
+    return check_launch("mtc_select_offsets_sharded");
+}
+
+extern "C" int mtc_select_pack_minmax(const mtc_select_state* st, int64_t* out2, void* stream) {
+    MTC_REQUIRE(st && out2, "mtc_select_pack_minmax: null pointer");
+    hipLaunchKernelGGL(select_pack_minmax_kernel, dim3(1), dim3(64), 0, as_stream(stream), st, reinterpret_cast<long long*>(out2));
+    return check_launch("mtc_select_pack_minmax");
+}
+
+extern "C" int mtc_threshold_ema_global(const mtc_desc* d, const int64_t* minmax2, void* threshold, float lr, void* stream) {
+    if (check_desc(d, "mtc_threshold_ema_global")) return -1;
+    MTC_REQUIRE(minmax2 && threshold, "mtc_threshold_ema_global: null pointer");
+    DISPATCH_DT(d->dtype, threshold_ema_global_kernel, dim3(1), dim3(64), 0, as_stream(stream),
+                reinterpret_cast<const long long*>(minmax2), threshold, lr);
+    return check_launch("mtc_threshold_ema_global");
+}
+
+extern "C" int mtc_shard_nnz_abs(const mtc_desc* d, const float* abs_rows, const mtc_select_state* st, float* out2, void* stream) {
+    if (check_desc(d, "mtc_shard_nnz_abs")) return -1;
+    MTC_REQUIRE(abs_rows && st && out2, "mtc_shard_nnz_abs: null pointer");
+    hipLaunchKernelGGL(nnz_abs_kernel, dim3(1), dim3(1024), 0, as_stream(stream), d->B, abs_rows, st, out2);
+    return check_launch("mtc_shard_nnz_abs");
 }
 
 extern "C" int mtc_threshold_ema(const mtc_desc* d, const mtc_select_state* st, void* threshold, float lr, void* stream) {

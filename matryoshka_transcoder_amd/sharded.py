@@ -181,24 +181,23 @@ class ShardedMatryoshkaTranscoder(MatryoshkaTranscoder):
                                              _p(row_eq), s), "mtc_select_finish_rows")
         else:
             check(lib.mtc_select_count(C.byref(d), _p(acts), _p(st), None, _p(row_gt), _p(row_eq), s), "mtc_select_count")
-        before = tie_before(self.comm.all_gather(row_eq), self.comm.rank).contiguous()
+        all_eq = self.comm.all_gather(row_eq).contiguous()                      # [world, B] per-row tie counts
         row_ptr = torch.empty(B + 1, dtype=torch.int32, device=dev)
         tie_take = torch.empty(B, dtype=torch.int32, device=dev)
-        check(lib.mtc_select_offsets(C.byref(d), _p(row_gt), _p(row_eq), _p(before), _p(st), _p(row_ptr), _p(tie_take), s),
-              "mtc_select_offsets")
+        check(lib.mtc_select_offsets_sharded(C.byref(d), _p(row_gt), _p(all_eq), self.comm.world, self.comm.rank, _p(st),
+                                             _p(row_ptr), _p(tie_take), s), "mtc_select_offsets_sharded")
         cap = max(k_total, 1)                       # a single rank can hold at most all k*B entries
         col_idx = torch.empty(cap, dtype=torch.int32, device=dev)
         vals = torch.empty(cap, dtype=self.dtype, device=dev)
         check(lib.mtc_select_fill(C.byref(d), _p(acts), _p(st), None, _p(row_ptr), _p(tie_take), _p(col_idx), _p(vals), s),
               "mtc_select_fill")
         sel = Selection(st, row_ptr, col_idx, vals)
-        # threshold EMA (a5) needs the GLOBAL smallest selected value and whether anything was selected
-        glob = torch.stack([st[6].to(torch.int64) & 0xffffffff, -st[7].to(torch.int64)])
+        # threshold EMA (a5) needs the GLOBAL smallest selected value and whether anything was selected:
+        # {min bits, -nnz} through one all-reduce(MIN)
+        glob = torch.empty(2, dtype=torch.int64, device=dev)
+        check(lib.mtc_select_pack_minmax(_p(st), _p(glob), s), "mtc_select_pack_minmax")
         self.comm.all_reduce(glob, op=dist.ReduceOp.MIN)
-        st_ema = st.clone()
-        st_ema[6] = torch.where(glob[0] >= 2 ** 31, glob[0] - 2 ** 32, glob[0]).to(torch.int32)
-        st_ema[7] = (-glob[1]).clamp(max=2 ** 31 - 1).to(torch.int32)          # max over ranks of the local nnz
-        hp.threshold_ema(d, Selection(st_ema, row_ptr, col_idx, vals), self.threshold)
+        check(lib.mtc_threshold_ema_global(C.byref(d), _p(glob), _p(self.threshold), 0.01, s), "mtc_threshold_ema_global")
         return sel
 
     # ------------------------------------------------------------------ step 3: decode + losses
@@ -303,19 +302,20 @@ class ShardedMatryoshkaTranscoder(MatryoshkaTranscoder):
         # reduce-scatter by batch rows: every rank finishes 1/W of the rows for all G prefixes
         my_last = self.comm.reduce_scatter(p_last)                         # [rps, A_t] fp32
         my_pre = self.comm.reduce_scatter(p_pre)[0] if G > 1 else None      # [G-1, rps, A_t]
-        nnz_abs = torch.stack([sel.state[7].to(torch.float32), abs_rows.sum()])
+        nnz_abs = torch.empty(2, dtype=torch.float32, device=dev)
+        check(lib.mtc_shard_nnz_abs(C.byref(d), _p(abs_rows), _p(sel.state), _p(nnz_abs), s), "mtc_shard_nnz_abs")
         self.comm.all_reduce(nnz_abs)
         dl = _lib.make_desc(rps, hp.A_s, hp.A_t, hp.D, hp.prefix, hp.code, hp.unit_norm)
         lo, hi = rank * rps, (rank + 1) * rps
-        x_hat_l = torch.empty(rps, A_t, dtype=self.dtype, device=dev)
-        g_l = torch.empty(rps, A_t, dtype=self.dtype, device=dev)
+        both_l = torch.empty(2, rps, A_t, dtype=self.dtype, device=dev)      # x_hat and g of this rank's rows, gathered together
+        x_hat_l, g_l = both_l[0], both_l[1]
         stats_l = torch.zeros(G + 4, rps, dtype=torch.float32, device=dev)
         check(lib.mtc_decode_finish(C.byref(dl), B, _p(my_last), _p(my_pre), _p(b_dec), _p(x_target[lo:hi]),
                                     _p(mean[lo:hi] if mean is not None else None),
                                     _p(std[lo:hi] if std is not None else None), _p(x_hat_l), _p(g_l), _p(stats_l), None, s),
               "mtc_decode_finish")
         # every rank needs all of g (its features fire on any row) and returns the full reconstruction
-        both = self.comm.all_gather(torch.stack([x_hat_l, g_l]))            # [W, 2, rps, A_t]
+        both = self.comm.all_gather(both_l)                                 # [W, 2, rps, A_t]
         x_hat = both[:, 0].reshape(B, A_t)
         g = both[:, 1].reshape(B, A_t).contiguous()
         row_stats = self.comm.all_gather(stats_l).permute(1, 0, 2).reshape(G + 4, B).contiguous()
