@@ -15,7 +15,8 @@ Step (RCCL through torch.distributed; every exchange is a real data dependency o
      all-gather of per-row tie counts ([world, B] ints);
   3. local sparse decode into bias-free per-prefix partial sums -> reduce-scatter over batch rows
      (last prefix fp32, earlier prefixes -- FVU only -- in the model dtype) -> each rank finishes
-     x_hat / per-prefix SSE / g for B/world rows -> all-gather of x_hat and g (model dtype);
+     x_hat / per-prefix SSE / g for B/world rows -> ONE all-gather of a packed byte buffer per rank
+     (x_hat and g of its rows, the per-row statistics, its nnz and sum|a|);
   4. backward and Adam are local to the shard (no gradient all-reduce); db_dec is identical
      everywhere because g is.
   5. while dead features exist: the auxiliary loss over shards (`_run_aux`): all-gather of per-row
@@ -302,23 +303,28 @@ class ShardedMatryoshkaTranscoder(MatryoshkaTranscoder):
         # reduce-scatter by batch rows: every rank finishes 1/W of the rows for all G prefixes
         my_last = self.comm.reduce_scatter(p_last)                         # [rps, A_t] fp32
         my_pre = self.comm.reduce_scatter(p_pre)[0] if G > 1 else None      # [G-1, rps, A_t]
-        nnz_abs = torch.empty(2, dtype=torch.float32, device=dev)
-        check(lib.mtc_shard_nnz_abs(C.byref(d), _p(abs_rows), _p(sel.state), _p(nnz_abs), s), "mtc_shard_nnz_abs")
-        self.comm.all_reduce(nnz_abs)
         dl = _lib.make_desc(rps, hp.A_s, hp.A_t, hp.D, hp.prefix, hp.code, hp.unit_norm)
         lo, hi = rank * rps, (rank + 1) * rps
-        both_l = torch.empty(2, rps, A_t, dtype=self.dtype, device=dev)      # x_hat and g of this rank's rows, gathered together
-        x_hat_l, g_l = both_l[0], both_l[1]
-        stats_l = torch.zeros(G + 4, rps, dtype=torch.float32, device=dev)
+        # one byte buffer per rank = {x_hat, g of its rows | per-row statistics | nnz, sum|a| of its shard}: ONE all-gather
+        # hands every rank all of g (its features fire on any row), the full reconstruction and the loss inputs
+        es = x_target.element_size()
+        n_xg, n_st = 2 * rps * A_t * es, (G + 4) * rps * 4
+        pack = torch.empty(n_xg + n_st + 8, dtype=torch.uint8, device=dev)
+        both_l = pack[:n_xg].view(self.dtype).view(2, rps, A_t)
+        stats_l = pack[n_xg:n_xg + n_st].view(torch.float32).view(G + 4, rps)
+        nnz_abs_l = pack[n_xg + n_st:].view(torch.float32)
+        stats_l.zero_()
+        check(lib.mtc_shard_nnz_abs(C.byref(d), _p(abs_rows), _p(sel.state), _p(nnz_abs_l), s), "mtc_shard_nnz_abs")
         check(lib.mtc_decode_finish(C.byref(dl), B, _p(my_last), _p(my_pre), _p(b_dec), _p(x_target[lo:hi]),
                                     _p(mean[lo:hi] if mean is not None else None),
-                                    _p(std[lo:hi] if std is not None else None), _p(x_hat_l), _p(g_l), _p(stats_l), None, s),
+                                    _p(std[lo:hi] if std is not None else None), _p(both_l[0]), _p(both_l[1]), _p(stats_l), None, s),
               "mtc_decode_finish")
-        # every rank needs all of g (its features fire on any row) and returns the full reconstruction
-        both = self.comm.all_gather(both_l)                                 # [W, 2, rps, A_t]
+        allp = self.comm.all_gather(pack)                                   # [W, bytes]
+        both = allp[:, :n_xg].view(self.dtype).view(W, 2, rps, A_t)
         x_hat = both[:, 0].reshape(B, A_t)
         g = both[:, 1].reshape(B, A_t).contiguous()
-        row_stats = self.comm.all_gather(stats_l).permute(1, 0, 2).reshape(G + 4, B).contiguous()
+        row_stats = allp[:, n_xg:n_xg + n_st].view(torch.float32).view(W, G + 4, rps).permute(1, 0, 2).reshape(G + 4, B).contiguous()
+        nnz_abs = allp[:, n_xg + n_st:].view(torch.float32).sum(0).contiguous()
         l1_term = float(cfg["l1_coeff"]) / (B * self.total_dict_size)
         x_hat = x_hat.contiguous()
         aux, aux_rows = None, None
