@@ -132,14 +132,17 @@ int mtc_select_global_topk_carry(const mtc_desc* d, const void* acts, uint32_t k
 /* Helpers of the feature-sharded caller (no counterpart in the single-process reference; each replaces a
  * handful of tiny tensor ops between two collectives):
  *   mtc_select_offsets_sharded : mtc_select_offsets with the tie order of a sharded dictionary -- ties are
- *       granted in (row, shard, feature) order from all_eq [world][B], the all-gathered per-row tie counts;
+ *       granted in (row, shard, feature) order from all_eq [world][eq_stride], the all-gathered per-row tie
+ *       counts; with eq_stride > B, all_eq[w][B] = shard w's smallest selected value (bits) and minmax_out
+ *       (optional) receives the pair mtc_threshold_ema_global consumes -- no extra collective for the EMA;
  *   mtc_select_pack_minmax     : out2 = {min selected bits, -nnz} (int64) for ONE all-reduce(MIN);
  *   mtc_threshold_ema_global   : a5 from that reduced pair (skipped when nothing was selected anywhere);
  *   mtc_shard_nnz_abs          : out2 = {nnz of this shard, sum |a| of its entries} for one all-reduce(SUM)
  *       that feeds mtc_reduce_scalars(nnz_abs_override). */
 int mtc_select_offsets_sharded(const mtc_desc* d, const uint32_t* row_gt, const uint32_t* all_eq,
-                               int32_t world, int32_t rank, mtc_select_state* st, int32_t* row_ptr,
-                               uint32_t* tie_take, void* stream);
+                               int32_t eq_stride, int32_t world, int32_t rank, mtc_select_state* st,
+                               int32_t* row_ptr, uint32_t* tie_take, int64_t* minmax_out,
+                               void* stream);
 int mtc_select_pack_minmax(const mtc_select_state* st, int64_t* out2, void* stream);
 int mtc_threshold_ema_global(const mtc_desc* d, const int64_t* minmax2, void* threshold, float lr,
                              void* stream);

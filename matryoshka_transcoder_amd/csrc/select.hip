@@ -555,10 +555,15 @@ __global__ __launch_bounds__(1024) void select_carry_decide_kernel(uint32_t* car
 // offsets with the tie order of a sharded dictionary: ties are granted in (row, shard, feature) order, so the
 // ties that precede this shard's row r are all ties of earlier rows (every shard) plus those of earlier shards in
 // row r.  all_eq [world][B] = the all-gathered per-row tie counts; the quota in st is the global one.
+// Row stride of all_eq is `stride` (>= B); with stride > B, all_eq[w][B] carries shard w's smallest selected value
+// (bits) and minmax_out receives {global min bits, -(anything selected anywhere)} for mtc_threshold_ema_global.
 __global__ __launch_bounds__(1024) void select_offsets_sharded_kernel(int B, const uint32_t* __restrict__ row_gt,
-                                                                      const uint32_t* __restrict__ all_eq, int world, int rank,
-                                                                      mtc_select_state* st, int32_t* __restrict__ row_ptr,
-                                                                      uint32_t* __restrict__ tie_take) {
+                                                                      const uint32_t* __restrict__ all_eq_, int stride, int world,
+                                                                      int rank, mtc_select_state* st, int32_t* __restrict__ row_ptr,
+                                                                      uint32_t* __restrict__ tie_take,
+                                                                      long long* __restrict__ minmax_out) {
+    const uint32_t* all_eq = all_eq_;
+#define B_STRIDE stride
     __shared__ uint32_t sm[16];
     const int t = threadIdx.x;
     const int per = (B + 1023) / 1024;
@@ -566,18 +571,18 @@ __global__ __launch_bounds__(1024) void select_offsets_sharded_kernel(int B, con
     const uint32_t quota = st->n_tie_take;
     uint32_t my_eq = 0;
     for (int r = r0; r < r1; ++r)
-        for (int w = 0; w < world; ++w) my_eq += all_eq[(size_t)w * B + r];
+        for (int w = 0; w < world; ++w) my_eq += all_eq[(size_t)w * B_STRIDE + r];
     uint32_t tot;
     uint32_t run = block_excl_scan_1024(my_eq, sm, &tot);
     uint32_t my_nnz = 0;
     for (int r = r0; r < r1; ++r) {
         uint32_t row_tot = 0, earlier = 0;
         for (int w = 0; w < world; ++w) {
-            const uint32_t e = all_eq[(size_t)w * B + r];
+            const uint32_t e = all_eq[(size_t)w * B_STRIDE + r];
             row_tot += e;
             if (w < rank) earlier += e;
         }
-        const uint32_t mine = all_eq[(size_t)rank * B + r];
+        const uint32_t mine = all_eq[(size_t)rank * B_STRIDE + r];
         const uint32_t before = run + earlier;
         const uint32_t take = before >= quota ? 0u : min(mine, quota - before);
         tie_take[r] = take;
@@ -594,7 +599,17 @@ __global__ __launch_bounds__(1024) void select_offsets_sharded_kernel(int B, con
         row_ptr[B] = (int32_t)nnz_total;
         st->nnz = nnz_total;
         if (quota > 0) st->min_sel_bits = min(st->min_sel_bits, st->tau_bits);
+        if (minmax_out && stride > B) {
+            uint32_t gmin = 0xffffffffu;
+            for (int w = 0; w < world; ++w) gmin = min(gmin, all_eq[(size_t)w * B_STRIDE + B]);
+            if (quota > 0) gmin = min(gmin, st->tau_bits);
+            // the histogram was all-reduced, so n_gt / the quota in st are global counts
+            const bool any = st->all_pos ? st->n_gt > 0 : (st->n_gt + st->n_tie_take) > 0;
+            minmax_out[0] = (long long)gmin;
+            minmax_out[1] = any ? -1ll : 0ll;
+        }
     }
+#undef B_STRIDE
 }
 
 // {min selected bits, -nnz} as int64 for ONE all-reduce(MIN) over the shards, and the EMA from its result
@@ -891,14 +906,15 @@ extern "C" int mtc_select_global_topk_carry(const mtc_desc* d, const void* acts,
     return fill_impl(d, d->D, acts, st, nullptr, row_ptr, tie_take, col_idx, vals, nullptr, flag, 0, stream);
 }
 
-extern "C" int mtc_select_offsets_sharded(const mtc_desc* d, const uint32_t* row_gt, const uint32_t* all_eq, int32_t world,
-                                          int32_t rank, mtc_select_state* st, int32_t* row_ptr, uint32_t* tie_take,
-                                          void* stream) {
+extern "C" int mtc_select_offsets_sharded(const mtc_desc* d, const uint32_t* row_gt, const uint32_t* all_eq, int32_t eq_stride,
+                                          int32_t world, int32_t rank, mtc_select_state* st, int32_t* row_ptr,
+                                          uint32_t* tie_take, int64_t* minmax_out, void* stream) {
     if (check_desc(d, "mtc_select_offsets_sharded")) return -1;
     MTC_REQUIRE(row_gt && all_eq && st && row_ptr && tie_take, "mtc_select_offsets_sharded: null pointer");
     MTC_REQUIRE(world >= 1 && rank >= 0 && rank < world, "mtc_select_offsets_sharded: bad rank %d of %d", rank, world);
-    hipLaunchKernelGGL(select_offsets_sharded_kernel, dim3(1), dim3(1024), 0, as_stream(stream), d->B, row_gt, all_eq, world,
-                       rank, st, row_ptr, tie_take);
+    MTC_REQUIRE(eq_stride >= d->B, "mtc_select_offsets_sharded: eq_stride %d < B %d", eq_stride, d->B);
+    hipLaunchKernelGGL(select_offsets_sharded_kernel, dim3(1), dim3(1024), 0, as_stream(stream), d->B, row_gt, all_eq, eq_stride,
+                       world, rank, st, row_ptr, tie_take, reinterpret_cast<long long*>(minmax_out));
     return check_launch("mtc_select_offsets_sharded");
 }
 

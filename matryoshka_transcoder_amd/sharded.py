@@ -164,7 +164,7 @@ class ShardedMatryoshkaTranscoder(MatryoshkaTranscoder):
         st = torch.empty(16, dtype=torch.int32, device=dev)
         check(lib.mtc_select_init(_p(st), k_total, s), "mtc_select_init")
         row_gt = torch.empty(B, dtype=torch.int32, device=dev)
-        row_eq = torch.empty(B, dtype=torch.int32, device=dev)
+        row_eq = torch.empty(B + 1, dtype=torch.int32, device=dev)      # [B] tie counts + this shard's smallest selected value
         bf16 = self.dtype == torch.bfloat16
         for level in range(1 if bf16 else lib.mtc_select_levels(C.byref(d))):
             hist = torch.zeros(4096, dtype=torch.int32, device=dev)
@@ -182,22 +182,20 @@ class ShardedMatryoshkaTranscoder(MatryoshkaTranscoder):
                                              _p(row_eq), s), "mtc_select_finish_rows")
         else:
             check(lib.mtc_select_count(C.byref(d), _p(acts), _p(st), None, _p(row_gt), _p(row_eq), s), "mtc_select_count")
-        all_eq = self.comm.all_gather(row_eq).contiguous()                      # [world, B] per-row tie counts
+        row_eq[B:].copy_(st[6:7])                                                # min_sel_bits rides with the tie counts
+        all_eq = self.comm.all_gather(row_eq).contiguous()                      # [world, B + 1]
         row_ptr = torch.empty(B + 1, dtype=torch.int32, device=dev)
         tie_take = torch.empty(B, dtype=torch.int32, device=dev)
-        check(lib.mtc_select_offsets_sharded(C.byref(d), _p(row_gt), _p(all_eq), self.comm.world, self.comm.rank, _p(st),
-                                             _p(row_ptr), _p(tie_take), s), "mtc_select_offsets_sharded")
+        glob = torch.empty(2, dtype=torch.int64, device=dev)
+        check(lib.mtc_select_offsets_sharded(C.byref(d), _p(row_gt), _p(all_eq), B + 1, self.comm.world, self.comm.rank, _p(st),
+                                             _p(row_ptr), _p(tie_take), _p(glob), s), "mtc_select_offsets_sharded")
         cap = max(k_total, 1)                       # a single rank can hold at most all k*B entries
         col_idx = torch.empty(cap, dtype=torch.int32, device=dev)
         vals = torch.empty(cap, dtype=self.dtype, device=dev)
         check(lib.mtc_select_fill(C.byref(d), _p(acts), _p(st), None, _p(row_ptr), _p(tie_take), _p(col_idx), _p(vals), s),
               "mtc_select_fill")
         sel = Selection(st, row_ptr, col_idx, vals)
-        # threshold EMA (a5) needs the GLOBAL smallest selected value and whether anything was selected:
-        # {min bits, -nnz} through one all-reduce(MIN)
-        glob = torch.empty(2, dtype=torch.int64, device=dev)
-        check(lib.mtc_select_pack_minmax(_p(st), _p(glob), s), "mtc_select_pack_minmax")
-        self.comm.all_reduce(glob, op=dist.ReduceOp.MIN)
+        # threshold EMA (a5): the global smallest selected value came with the tie-count gather
         check(lib.mtc_threshold_ema_global(C.byref(d), _p(glob), _p(self.threshold), 0.01, s), "mtc_threshold_ema_global")
         return sel
 
