@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Copies the summaries tools/measure.sh left under gpurun_out/ into profiles/ (kernel stats CSV, bench line,
+per-kernel HBM-side traffic from the FETCH_SIZE / WRITE_SIZE passes with the gfx950 correction)."""
+import collections
+import csv
+import json
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+out = {}
+for kind, path in (("fetch", "gpurun_out/pmc_fetch/f_counter_collection.csv"), ("write", "gpurun_out/pmc_write/w_counter_collection.csv")):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    for k, v in agg.items():
+        out.setdefault(k, {})[kind] = sum(v) / len(v)
+        out[k]["n"] = len(v)
+kernels = {}
+for k, v in out.items():
+    f, w = v.get("fetch", 0.0), v.get("write", 0.0)
+    if f + w < 1000:
+        continue
+    kernels[k.split("(")[0].replace("void ", "")] = {
+        "fetch_KiB_raw": round(f, 1), "write_KiB_raw": round(w, 1),
+        "hbm_bytes_per_launch": int(f * 1024 * 2 + w * 1024), "launches_sampled": v["n"]}
+doc = {
+    "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) --output-format csv -- python3 bench.py "
+               "--no-cpu-baseline --steps 4 --warmup 2",
+    "correction": "MI355X_MICROARCH.md HBM section: FETCH_SIZE counts 128-B requests at 64 B on gfx950 -> x2 for wide "
+                  "coalesced reads; WRITE_SIZE exact for 16-B-per-lane stores; both in KiB.  Checked on the select passes: "
+                  "they read acts once (301,989,888 B) and report ~147.6k KiB raw.  Infinity Cache hits are counted "
+                  "(memory side of L2), so these are fabric bytes, an upper bound of HBM bytes.",
+    "workload": "gemma2-2b bf16, B 4096", "kernels": kernels}
+json.dump(doc, open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1)
+shutil.copy(f"gpurun_out/prof_{tag}/{tag}_kernel_stats.csv", f"profiles/{tag}_kernel_stats.csv")
+shutil.copy(f"gpurun_out/bench_{tag}.json", f"profiles/{tag}_bench_line.json")
+print("profiles updated for", tag)

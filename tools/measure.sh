@@ -1,0 +1,22 @@
+#!/bin/bash
+# Runs on the GPU box (gpurun -- 'bash tools/measure.sh TAG'): GPU tests, smoke, bench with cpu_baseline, rocprofv3 kernel
+# stats and the two PMC passes; everything lands under gpurun_out/.  tools/collect_profiles.py TAG then copies the
+# summaries into profiles/.
+set -o pipefail
+TAG=${1:-r01}
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out
+timeout -k 10 600 python -u -m pytest tests -m gpu -x -q --timeout 200 --timeout-method thread > gpurun_out/gpu_tests.log 2>&1 || { tail -20 gpurun_out/gpu_tests.log; exit 1; }
+tail -1 gpurun_out/gpu_tests.log
+timeout -k 10 200 python -u -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1 || { tail -5 gpurun_out/smoke.log; exit 1; }
+tail -1 gpurun_out/smoke.log
+timeout -k 10 300 python -u bench.py > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -o $TAG -- python3 bench.py --no-cpu-baseline --steps 30 --warmup 5 > gpurun_out/bench_prof.json 2> gpurun_out/bench_prof.err || exit 1
+timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -o f -- python3 bench.py --no-cpu-baseline --steps 4 --warmup 2 > gpurun_out/pmc_fetch.log 2>&1 || exit 1
+timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -o w -- python3 bench.py --no-cpu-baseline --steps 4 --warmup 2 > gpurun_out/pmc_write.log 2>&1 || exit 1
+python3 - <<PY
+import json
+r = json.load(open("gpurun_out/bench_$TAG.json"))
+print(r["value"], r["ms_per_step"], r["roofline"]["frac"], r["cpu_baseline"]["value"])
+print({k: round(v["ms"], 3) for k, v in r["stages"].items()})
+PY
