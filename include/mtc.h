@@ -290,6 +290,22 @@ int mtc_aux_fwd(const mtc_desc* d, const int32_t* row_ptr, const int32_t* col_id
 int mtc_densify(const mtc_desc* d, const int32_t* row_ptr, const int32_t* col_idx, const void* vals,
                 int32_t max_col, void* dense, void* stream);
 
+/* SURVEY 8f row 4 -- top-activating-sample tables (replaces ActivationSampleCollector.collect_batch_samples /
+ * _add_sample, src/utils/activation_samples.py:83-183, called from training.py:138-152).
+ * Input: the CSC view (col_ptr[D+1], csc_row, csc_pos -> vals in the model dtype) of the sparse activations of
+ * n_rows = batch*seq_len token positions, and tokens[batch][seq_len] (int64, ids < 2^31).  Every entry with
+ * value > storage_threshold counts into feat_count[D] / feat_max[D]; per feature the max_samples (1..256) largest
+ * are kept across calls in top_val[D][M] (descending, -inf = empty) / top_slot[D][M] (a permutation of 0..M-1 per
+ * feature; initialise to 0..M-1 and -inf), with per slot slot_meta[D][M][4] = {sequence position, window length,
+ * token before the position or -1, flat row} and slot_ctx[D][M][2*(context_size/2)+1] = the token window
+ * [pos - context_size/2, pos + context_size/2] clipped to the sequence.  Equal values: the older sample stays.
+ * track (optional uint8[D]): features with 0 are skipped (the reference's feature_indices). */
+int mtc_collect_top_samples(int32_t dtype, int32_t n_rows, int32_t D, int32_t seq_len, const int32_t* col_ptr,
+                            const int32_t* csc_row, const int32_t* csc_pos, const void* vals, const int64_t* tokens,
+                            const uint8_t* track, float storage_threshold, int32_t max_samples, int32_t context_size,
+                            float* top_val, int32_t* top_slot, int32_t* slot_meta, int32_t* slot_ctx,
+                            uint64_t* feat_count, float* feat_max, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -67,6 +67,13 @@ class CleanResultsManager:
             with path.open("w", encoding="utf-8") as f:
                 json.dump(_jsonable(metrics), f, indent=2)
 
+    def save_activation_samples(self, experiment_dir: Path, sample_collector: Any, top_k_features: int = 100,
+                                samples_per_feature: int = 10) -> None:
+        """clean_results.py:88-97: {run}/activation_samples/feature_%05d_samples.json + collection_summary.json."""
+        samples_dir = Path(experiment_dir) / "activation_samples"
+        samples_dir.mkdir(exist_ok=True)
+        sample_collector.save_samples(str(samples_dir), top_k_features, samples_per_feature)
+
     def list_experiments(self, model_name: Optional[str] = None, layer: Optional[int] = None) -> Dict[str, Any]:
         found: Dict[str, Any] = {}
         for mdir in sorted(p for p in self.base_dir.iterdir() if p.is_dir()):

@@ -15,6 +15,7 @@ from typing import Optional
 import torch
 
 from . import _lib
+from .activation_samples import ActivationSampleCollector
 from .engine import adam_hyper
 from .results import CleanResultsManager
 
@@ -158,6 +159,12 @@ def train_transcoder(transcoder, activation_store, model, cfg):
     n_dead_at = cfg.get("n_batches_to_dead", 20)
     out = None
     t0 = time.time()
+    sample_collector = None
+    if cfg.get("save_activation_samples", False):       # training.py:77-85
+        sample_collector = ActivationSampleCollector(
+            max_samples_per_feature=cfg.get("max_samples_per_feature", 100),
+            context_size=cfg.get("sample_context_size", 20),
+            storage_threshold=cfg.get("sample_activation_threshold", 0.1))
 
     def metrics_of(o):
         return {"loss": float(o["loss"].detach()), "l2_loss": float(o["l2_loss"].detach()),
@@ -169,7 +176,8 @@ def train_transcoder(transcoder, activation_store, model, cfg):
             source_batch, target_batch = activation_store.next_batch()
             perf_now = i % cfg.get("perf_log_freq", 1000) == 0
             ckpt_now = i % cfg.get("checkpoint_freq", 10000) == 0
-            if perf_now or ckpt_now:
+            sample_now = sample_collector is not None and i % cfg.get("sample_collection_freq", 1000) == 0
+            if perf_now or ckpt_now or sample_now:
                 # the reference logs performance / checkpoints between the forward and the update
                 # (training.py:92-171): keep that order with the autograd path on those iterations
                 out = transcoder(source_batch, target_batch)
@@ -177,6 +185,8 @@ def train_transcoder(transcoder, activation_store, model, cfg):
                     log_transcoder_performance(log, i, model, activation_store, transcoder)
                 if ckpt_now:
                     results.save_checkpoint(exp_dir, transcoder, cfg, i, metrics_of(out), is_final=False)
+                if sample_now:
+                    collect_activation_samples(sample_collector, transcoder, activation_store)
                 out["loss"].backward()
                 optimizer.step(project=True)      # unit-norm projection fused into the W_dec update
                 optimizer.zero_grad()
@@ -193,7 +203,20 @@ def train_transcoder(transcoder, activation_store, model, cfg):
     final_cfg["completed_steps"] = num_batches
     if out is not None:
         results.save_checkpoint(exp_dir, transcoder, final_cfg, num_batches, metrics_of(out), is_final=True)
+    if sample_collector is not None:
+        results.save_activation_samples(exp_dir, sample_collector, cfg.get("top_features_to_save", 100),
+                                        cfg.get("samples_per_feature_to_save", 10))
     return exp_dir
+
+
+def collect_activation_samples(sample_collector, transcoder, activation_store):
+    """training.py:138-152: a batch with its tokens through `encode` (in the transcoder's current mode, so in
+    training mode this is a global-TopK encode that moves the threshold EMA, as in the reference), then into the
+    device tables.  Runs between the forward and the update of its iteration, like the reference."""
+    source, tokens = activation_store.get_batch_with_tokens()
+    with torch.no_grad():
+        features = transcoder.encode(source)
+    sample_collector.collect_batch_samples(features, tokens, activation_store.tokenizer)
 
 
 def log_transcoder_performance(log, step, model, activation_store, transcoder):
