@@ -89,5 +89,9 @@ def test_reference_import_paths():
     from src.models.transcoder_activation_store import TranscoderActivationsStore, create_transcoder_config  # noqa: F401
     from src.utils.config import get_default_cfg  # noqa: F401
     from src.utils.clean_results import CleanResultsManager  # noqa: F401
+    from src.utils.activation_samples import ActivationSampleCollector  # noqa: F401
+    from eval.sae_bench import build_matryoshka_adapter, build_npz_transcoder_adapter  # noqa: F401
+    from eval.sae_bench.wrappers import MatryoshkaAutoInterpAdapter
+    from eval.sae_bench.config import NPZTranscoderSpec  # noqa: F401
     from matryoshka_transcoder_amd.transcoder import MatryoshkaTranscoder as B
-    assert A is B
+    assert A is B and issubclass(MatryoshkaAutoInterpAdapter, B)

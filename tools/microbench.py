@@ -59,7 +59,15 @@ def main():
     def flush():
         big.zero_()          # 512 MiB write: evicts L2 / Infinity Cache between repetitions
 
+    # side path: top-sample tables fed with the batch's selection (B positions = B/128 sequences of 128 tokens)
+    from matryoshka_transcoder_amd.activation_samples import ActivationSampleCollector
+    col = ActivationSampleCollector(100, 20, 0.1)
+    toks = torch.randint(0, 250000, (B // 128, 128), device=dev)
+    dense = hp.densify(d, sel, D)
+
     tests = {
+        "collect_selection": lambda: col.collect_selection(sel, dt, B, D, toks, None),
+        "collect_dense": lambda: col.collect_batch_samples(dense, toks, None),
         "encode": lambda: hp.encode(d, xs, W_encT, b_enc),
         "select_topk": lambda: hp.select_topk(d, acts, k * B),
         "select_topk_carry": lambda: hp.select_topk(d, acts, k * B, carry=True),
