@@ -73,6 +73,12 @@ int mtc_row_normalize(const mtc_desc* d, const void* x, void* x_norm, void* mean
 int mtc_encode_fwd(const mtc_desc* d, const void* x, const void* W_encT, const void* b_enc,
                    void* acts, void* stream);
 
+/* a4 / a15  eval-mode encode (sae.py:189-191 inside encode, sae.py:363-387): the same encoder with
+ * where(acts > threshold, acts, 0) applied in its epilogue, so the dense feature tensor `feats` [B][D] the API
+ * returns is written once and never re-read.  threshold: device scalar in the model dtype (the module's buffer). */
+int mtc_encode_threshold_infer(const mtc_desc* d, const void* x, const void* W_encT, const void* b_enc,
+                               const void* threshold, void* feats, void* stream);
+
 /* a3  global batch-TopK (sae.py:176-187) as an exact k-th-largest threshold select over the
  * B*D activations; a5 threshold EMA input (sae.py:358-360) falls out as min_sel_bits.
  * Phases are separate entry points so a feature-sharded caller can all-reduce `hist` between

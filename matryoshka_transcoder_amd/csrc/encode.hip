@@ -95,9 +95,19 @@ __device__ __forceinline__ void xcd_tile_coords(int bid, int nblk, int mt, int n
     tn = in / gsz;
 }
 
-// ReLU that never emits -0.0 (the select reads bit patterns), packed to 4 bf16
-__device__ __forceinline__ uint2 relu_pack4(float p0, float p1, float p2, float p3) {
-    p0 = p0 > 0.f ? p0 : 0.f; p1 = p1 > 0.f ? p1 : 0.f; p2 = p2 > 0.f ? p2 : 0.f; p3 = p3 > 0.f ? p3 : 0.f;
+// Epilogue floor: 0 for the training encoder (plain ReLU); max(threshold, 0) when the eval-mode threshold
+// (sae.py:189-191: where(relu(pre) > threshold, ., 0)) is fused in.  A NaN threshold keeps nothing, like the
+// reference's comparison.
+template <int DT>
+__device__ __forceinline__ float epilogue_floor(const void* thr) {
+    if (!thr) return 0.f;
+    const float t = DType<DT>::ld(reinterpret_cast<const typename DType<DT>::T*>(thr));
+    return t != t ? t : fmaxf(t, 0.f);
+}
+
+// ReLU / threshold that never emits -0.0 (the select reads bit patterns), packed to 4 bf16
+__device__ __forceinline__ uint2 relu_pack4(float p0, float p1, float p2, float p3, float fl) {
+    p0 = p0 > fl ? p0 : 0.f; p1 = p1 > fl ? p1 : 0.f; p2 = p2 > fl ? p2 : 0.f; p3 = p3 > fl ? p3 : 0.f;
     uint2 o;
     o.x = (__float_as_uint(p0) >> 16) | (__float_as_uint(p1) & 0xffff0000u);
     o.y = (__float_as_uint(p2) >> 16) | (__float_as_uint(p3) & 0xffff0000u);
@@ -111,7 +121,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
 
 __global__ __launch_bounds__(256, 2) void encode_bf16_mfma_kernel(const u16* __restrict__ X, const u16* __restrict__ Wt,
                                                                   const u16* __restrict__ bias, u16* __restrict__ acts,
-                                                                  int M, int N, int K, int mt, int nt) {
+                                                                  int M, int N, int K, int mt, int nt, const void* __restrict__ thr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // layout: [stage][operand(0 = X, 1 = W)][128 rows][128 B]
     int tm, tn;
@@ -187,6 +197,7 @@ __global__ __launch_bounds__(256, 2) void encode_bf16_mfma_kernel(const u16* __r
     // ---- epilogue: lane holds features f = fbase + i*16 + fq*4 + r (r = 0..3) of batch row b = bbase + j*16 + fr
     const int fbase = col0 + wf * 64 + fq * 4;
     const int bbase = row0 + wb * 64 + fr;
+    const float fl = epilogue_floor<MTC_BF16>(thr);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int f = fbase + i * 16;
@@ -201,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void encode_bf16_mfma_kernel(const u16* __r
             const f32x4 v = acc[i][j];
             *reinterpret_cast<uint2*>(acts + (size_t)b * N + f) =
                 relu_pack4(round_bf16(round_bf16(v[0]) + b0), round_bf16(round_bf16(v[1]) + b1),
-                           round_bf16(round_bf16(v[2]) + b2), round_bf16(round_bf16(v[3]) + b3));
+                           round_bf16(round_bf16(v[2]) + b2), round_bf16(round_bf16(v[3]) + b3), fl);
         }
     }
 }
@@ -215,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void encode_bf16_mfma_kernel(const u16* __r
 constexpr int BK32 = 32;
 __global__ __launch_bounds__(256, 2) void encode_f32_mfma_kernel(const float* __restrict__ X, const float* __restrict__ Wt,
                                                                  const float* __restrict__ bias, float* __restrict__ acts,
-                                                                 int M, int N, int K, int mt, int nt) {
+                                                                 int M, int N, int K, int mt, int nt, const void* __restrict__ thr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int tm, tn;
     xcd_tile_coords(blockIdx.x, mt * nt, mt, nt, tm, tn);
@@ -287,6 +298,7 @@ __global__ __launch_bounds__(256, 2) void encode_f32_mfma_kernel(const float* __
     // ---- epilogue: lane holds features f = fbase + i*16 + r (r = 0..3) of batch row b = bbase + j*16
     const int fbase = col0 + wf * 64 + fq * 4;
     const int bbase = row0 + wb * 64 + fr;
+    const float fl = epilogue_floor<MTC_F32>(thr);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int f = fbase + i * 16;
@@ -298,7 +310,7 @@ __global__ __launch_bounds__(256, 2) void encode_f32_mfma_kernel(const float* __
             if (b >= M) continue;
             f32x4 v = acc[i][j];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { const float pre = v[r] + bb[r]; v[r] = pre > 0.f ? pre : 0.f; }
+            for (int r = 0; r < 4; ++r) { const float pre = v[r] + bb[r]; v[r] = pre > fl ? pre : 0.f; }
             *reinterpret_cast<f32x4*>(acts + (size_t)b * N + f) = v;
         }
     }
@@ -360,7 +372,7 @@ __device__ __forceinline__ void mfma_quadrant(bf16x8 (&wf)[2][4], bf16x8 (&xf)[2
 
 __global__ __launch_bounds__(512, 1) void encode_bf16_mfma256_kernel(const u16* __restrict__ X, const u16* __restrict__ Wt,
                                                                      const u16* __restrict__ bias, u16* __restrict__ acts,
-                                                                     int M, int N, int K, int mt, int nt) {
+                                                                     int M, int N, int K, int mt, int nt, const void* __restrict__ thr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int tm, tn;
     xcd_tile_coords(blockIdx.x, mt * nt, mt, nt, tm, tn);
@@ -471,6 +483,7 @@ __global__ __launch_bounds__(512, 1) void encode_bf16_mfma256_kernel(const u16* 
     // ---- epilogue: lane holds features f = fbase + i*16 + r (r = 0..3) of batch row b = bbase + j*16
     const int fbase = col0 + wr * 128 + fq * 4;
     const int bbase = row0 + wc * 64 + fr;
+    const float fl = epilogue_floor<MTC_BF16>(thr);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int f = fbase + i * 16;
@@ -485,7 +498,7 @@ __global__ __launch_bounds__(512, 1) void encode_bf16_mfma256_kernel(const u16* 
             const f32x4 v = acc[i][j];
             *reinterpret_cast<uint2*>(acts + (size_t)b * N + f) =
                 relu_pack4(round_bf16(round_bf16(v[0]) + b0), round_bf16(round_bf16(v[1]) + b1),
-                           round_bf16(round_bf16(v[2]) + b2), round_bf16(round_bf16(v[3]) + b3));
+                           round_bf16(round_bf16(v[2]) + b2), round_bf16(round_bf16(v[3]) + b3), fl);
         }
     }
 }
@@ -496,7 +509,7 @@ __global__ __launch_bounds__(512, 1) void encode_bf16_mfma256_kernel(const u16* 
 template <int DT>
 __global__ __launch_bounds__(256) void encode_generic_kernel(const void* __restrict__ X, const void* __restrict__ Wt,
                                                              const void* __restrict__ bias, void* __restrict__ acts,
-                                                             int M, int N, int K) {
+                                                             int M, int N, int K, const void* __restrict__ thr) {
     typedef DType<DT> D_;
     typedef typename D_::T T;
     __shared__ float xs[16][64 + 4];
@@ -529,6 +542,7 @@ __global__ __launch_bounds__(256) void encode_generic_kernel(const void* __restr
     }
     T* out = reinterpret_cast<T*>(acts);
     const T* bp = reinterpret_cast<const T*>(bias);
+    const float fl = epilogue_floor<DT>(thr);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = row0 + ty * 4 + i;
@@ -538,7 +552,7 @@ __global__ __launch_bounds__(256) void encode_generic_kernel(const void* __restr
             const int c = col0 + tx * 4 + j;
             if (c >= N) continue;
             const float pre = D_::rnd(D_::rnd(acc[i][j]) + D_::ld(bp + c));
-            D_::st(out + (size_t)r * N + c, pre > 0.f ? pre : 0.f);
+            D_::st(out + (size_t)r * N + c, pre > fl ? pre : 0.f);
         }
     }
 }
@@ -560,10 +574,8 @@ extern "C" int mtc_row_normalize(const mtc_desc* d, const void* x, void* x_norm,
     return check_launch("mtc_row_normalize");
 }
 
-extern "C" int mtc_encode_fwd(const mtc_desc* d, const void* x, const void* W_encT, const void* b_enc, void* acts,
-                              void* stream) {
-    if (check_desc(d, "mtc_encode_fwd")) return -1;
-    MTC_REQUIRE(x && W_encT && b_enc && acts, "mtc_encode_fwd: null pointer");
+static int encode_impl(const mtc_desc* d, const void* x, const void* W_encT, const void* b_enc, const void* thr,
+                       void* acts, void* stream) {
     const int M = d->B, N = d->D, K = d->A_s;
     if (d->dtype == MTC_F32 && (K % BK32) == 0 && !(getenv("MTC_ENCODE_F32_GENERIC"))) {
         const int lds = 2 * 2 * TILE_BYTES;
@@ -571,7 +583,7 @@ extern "C" int mtc_encode_fwd(const mtc_desc* d, const void* x, const void* W_en
         const int mt = (M + BM - 1) / BM, nt = (N + BN - 1) / BN;
         hipLaunchKernelGGL(encode_f32_mfma_kernel, dim3(mt * nt), dim3(256), lds, as_stream(stream),
                            reinterpret_cast<const float*>(x), reinterpret_cast<const float*>(W_encT),
-                           reinterpret_cast<const float*>(b_enc), reinterpret_cast<float*>(acts), M, N, K, mt, nt);
+                           reinterpret_cast<const float*>(b_enc), reinterpret_cast<float*>(acts), M, N, K, mt, nt, thr);
         return check_launch("mtc_encode_fwd");
     }
     const char* force = getenv("MTC_ENCODE_TILE");
@@ -582,20 +594,34 @@ extern "C" int mtc_encode_fwd(const mtc_desc* d, const void* x, const void* W_en
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         const int mt = (M + B2M - 1) / B2M, nt = (N + B2N - 1) / B2N;
         hipLaunchKernelGGL(encode_bf16_mfma256_kernel, dim3(mt * nt), dim3(512), lds, as_stream(stream),
-                           (const u16*)x, (const u16*)W_encT, (const u16*)b_enc, (u16*)acts, M, N, K, mt, nt);
+                           (const u16*)x, (const u16*)W_encT, (const u16*)b_enc, (u16*)acts, M, N, K, mt, nt, thr);
     } else if (d->dtype == MTC_BF16 && (K % BK) == 0) {
         const int lds = 2 * 2 * TILE_BYTES;
         hipFuncSetAttribute(reinterpret_cast<const void*>(encode_bf16_mfma_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         const int mt = (M + BM - 1) / BM, nt = (N + BN - 1) / BN;
         hipLaunchKernelGGL(encode_bf16_mfma_kernel, dim3(mt * nt), dim3(256), lds, as_stream(stream),
-                           (const u16*)x, (const u16*)W_encT, (const u16*)b_enc, (u16*)acts, M, N, K, mt, nt);
+                           (const u16*)x, (const u16*)W_encT, (const u16*)b_enc, (u16*)acts, M, N, K, mt, nt, thr);
     } else {
         const dim3 grid((N + 63) / 64, (M + 63) / 64), block(256);
         if (d->dtype == MTC_BF16)
-            hipLaunchKernelGGL(encode_generic_kernel<MTC_BF16>, grid, block, 0, as_stream(stream), x, W_encT, b_enc, acts, M, N, K);
+            hipLaunchKernelGGL(encode_generic_kernel<MTC_BF16>, grid, block, 0, as_stream(stream), x, W_encT, b_enc, acts, M, N, K, thr);
         else
-            hipLaunchKernelGGL(encode_generic_kernel<MTC_F32>, grid, block, 0, as_stream(stream), x, W_encT, b_enc, acts, M, N, K);
+            hipLaunchKernelGGL(encode_generic_kernel<MTC_F32>, grid, block, 0, as_stream(stream), x, W_encT, b_enc, acts, M, N, K, thr);
     }
     return check_launch("mtc_encode_fwd");
+}
+
+extern "C" int mtc_encode_fwd(const mtc_desc* d, const void* x, const void* W_encT, const void* b_enc, void* acts,
+                              void* stream) {
+    if (check_desc(d, "mtc_encode_fwd")) return -1;
+    MTC_REQUIRE(x && W_encT && b_enc && acts, "mtc_encode_fwd: null pointer");
+    return encode_impl(d, x, W_encT, b_enc, nullptr, acts, stream);
+}
+
+extern "C" int mtc_encode_threshold_infer(const mtc_desc* d, const void* x, const void* W_encT, const void* b_enc,
+                                          const void* threshold, void* feats, void* stream) {
+    if (check_desc(d, "mtc_encode_threshold_infer")) return -1;
+    MTC_REQUIRE(x && W_encT && b_enc && threshold && feats, "mtc_encode_threshold_infer: null pointer");
+    return encode_impl(d, x, W_encT, b_enc, threshold, feats, stream);
 }

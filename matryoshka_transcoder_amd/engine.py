@@ -107,6 +107,16 @@ class HotPath:
         check(self.lib.mtc_encode_fwd(C.byref(d), _p(x_norm), _p(W_encT), _p(b_enc), _p(acts), _stream()), "mtc_encode_fwd")
         return acts
 
+    def encode_threshold(self, d, x_norm, W_encT, b_enc, threshold):
+        """a4 + a15: eval-mode dense features in ONE launch (threshold applied in the encoder's epilogue)."""
+        _need(W_encT, "W_encT", self.dtype, (self.D, self.A_s))
+        _need(b_enc, "b_enc", self.dtype, (self.D,))
+        thr = threshold.reshape(1).to(self.dtype).contiguous()
+        feats = torch.empty(d.B, self.D, dtype=self.dtype, device=x_norm.device)
+        check(self.lib.mtc_encode_threshold_infer(C.byref(d), _p(x_norm), _p(W_encT), _p(b_enc), _p(thr), _p(feats),
+                                                  _stream()), "mtc_encode_threshold_infer")
+        return feats
+
     # ------------------------------------------------------------------ a3 select / a4 threshold
     def carry_state(self, device) -> torch.Tensor:
         key = str(device)

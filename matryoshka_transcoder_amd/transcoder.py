@@ -306,9 +306,14 @@ class MatryoshkaTranscoder(nn.Module):
         self._check_inputs(x2)
         hp = self.hot_path()
         d = hp.desc(x2.shape[0])
-        acts = hp.encode(d, x2, self._w_encT(self.W_enc), self.b_enc)
-        sel = self._select(hp, d, acts, self.training)
-        result = hp.densify(d, sel, self.prefix_indices[self.active_prefixes])
+        max_col = self.prefix_indices[self.active_prefixes]
+        if not self.training and max_col == hp.D:
+            # eval mode: the threshold rides in the encoder's epilogue; the dense result is written once
+            result = hp.encode_threshold(d, x2, self._w_encT(self.W_enc), self.b_enc, self.threshold)
+        else:
+            acts = hp.encode(d, x2, self._w_encT(self.W_enc), self.b_enc)
+            sel = self._select(hp, d, acts, self.training)
+            result = hp.densify(d, sel, max_col)
         if len(original_shape) == 3:
             result = result.reshape(original_shape[0], original_shape[1], -1)
         return result

@@ -188,7 +188,7 @@ def test_full_size_properties_gemma2_2b(gpu_lib):
         assert bool((gW[~fired.to(DEV)] == 0).all())                 # silent features: zero gradient rows
         opt.step(project=True)
         opt.zero_grad()
-        losses.append(float(out["loss"].float()))
+        losses.append(float(out["loss"].detach().float()))
         assert float(out["fvu_min"]) <= float(out["fvu_mean"]) <= float(out["fvu_max"])
     norms = m.W_dec.detach().float().norm(dim=-1)
     assert float((norms - 1).abs().max()) < 2e-2                     # rows stay ~unit norm (post-Adam drift only)

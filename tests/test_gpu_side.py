@@ -196,3 +196,28 @@ def test_training_loop_collects_samples(gpu_lib, tmp_path):
     assert "collection_summary.json" in files and len([f for f in files if f.startswith("feature_")]) == 5
     data = json.load(open(exp / "activation_samples" / [f for f in files if f.startswith("feature_")][0]))
     assert 1 <= len(data["top_samples"]) <= 3 and data["top_samples"][0]["context_text"].startswith("t")
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(37, 48, 264), (300, 64, 1024), (1024, 128, 4096)])
+def test_fused_threshold_encode_equals_select_path(gpu_lib, dt, shape):
+    """Eval-mode encode (sae.py:189-191,363-387): the threshold fused into the encoder epilogue gives bit for bit
+    the dense tensor of encoder -> threshold select -> densify, on every encoder kernel (generic, 128^2 bf16 / fp32
+    MFMA tiles; the 256^2 kernel shares the epilogue and is covered by the eval fixtures at full size in bench)."""
+    from matryoshka_transcoder_amd.engine import HotPath
+    B, A, D = shape
+    g = torch.Generator("cpu").manual_seed(B)
+    hp = HotPath(A, A, [D // 4, D], dt, False)
+    d = hp.desc(B)
+    x = torch.randn(B, A, generator=g).to(dt).cuda()
+    W = (torch.randn(D, A, generator=g) / A ** 0.5).to(dt).cuda()
+    b = (torch.randn(D, generator=g) * 0.1).to(dt).cuda()
+    acts = hp.encode(d, x, W, b)
+    for thr in (0.3, 0.0, -1.0, float("nan")):
+        t = torch.tensor(thr, dtype=dt, device="cuda")
+        fused = hp.encode_threshold(d, x, W, b, t)
+        want = torch.where(acts > t, acts, torch.zeros_like(acts))
+        assert torch.equal(fused, want), thr
+        if thr == thr:
+            sel = hp.select_threshold(d, acts, t)
+            assert torch.equal(hp.densify(d, sel, D), fused)
