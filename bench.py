@@ -24,6 +24,13 @@ WORKLOADS = {
     # name: (A, group sizes as BASELINE.json lists them, top_k, batch)
     "gemma2-2b": (2304, [2304, 4608, 9216, 20736], 96, 4096),
     "gpt2": (768, [768, 1536, 3072, 6912], 64, 1024),
+    # the other BASELINE configs (quoted there on 8 GPUs; they fit one MI355X) -- swept by tools/sweep.py
+    "gemma2-9b": (3584, [1792, 1792, 3584, 7168, 14336, 28672], 128, 8192),
+    "gemma2-27b": (4608, [4608, 9216, 18432, 41472], 184, 16384),
+    "gemma2-27b-2x": (4608, [9216, 18432, 36864, 82944], 184, 16384),
+    # the README lists taken literally as cumulative prefix_sizes (what the reference code would build from them)
+    "gpt2-literal": (768, [768, 768, 1536, 3840], 64, 1024),
+    "gemma2-2b-literal": (2304, [2304, 2304, 4608, 11520], 96, 4096),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_BF16_PEAK_TF = 2500.0     # dense bf16
@@ -189,7 +196,7 @@ def main():
 
     result = {
         "metric": "train tokens/sec (fwd+bwd+Adam), Gemma-2-2B d=36864 k=96" if args.workload == "gemma2-2b"
-        else "train tokens/sec (fwd+bwd+Adam), GPT-2 small d=12288 k=64",
+        else f"train tokens/sec (fwd+bwd+Adam), {args.workload} d={D} k={k}",
         "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",

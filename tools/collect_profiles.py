@@ -35,4 +35,5 @@ doc = {
 json.dump(doc, open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1)
 shutil.copy(f"gpurun_out/prof_{tag}/{tag}_kernel_stats.csv", f"profiles/{tag}_kernel_stats.csv")
 shutil.copy(f"gpurun_out/bench_{tag}.json", f"profiles/{tag}_bench_line.json")
+shutil.copy("gpurun_out/sweep.json", f"profiles/{tag}_sweep.json")
 print("profiles updated for", tag)

@@ -14,6 +14,7 @@ timeout -k 10 300 python -u bench.py > gpurun_out/bench_$TAG.json 2> gpurun_out/
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -o $TAG -- python3 bench.py --no-cpu-baseline --steps 30 --warmup 5 > gpurun_out/bench_prof.json 2> gpurun_out/bench_prof.err || exit 1
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -o f -- python3 bench.py --no-cpu-baseline --steps 4 --warmup 2 > gpurun_out/pmc_fetch.log 2>&1 || exit 1
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -o w -- python3 bench.py --no-cpu-baseline --steps 4 --warmup 2 > gpurun_out/pmc_write.log 2>&1 || exit 1
+timeout -k 10 600 python -u tools/sweep.py > gpurun_out/sweep.log 2>&1 || { tail -5 gpurun_out/sweep.log; exit 1; }
 python3 - <<PY
 import json
 r = json.load(open("gpurun_out/bench_$TAG.json"))
