@@ -221,3 +221,39 @@ def test_fused_threshold_encode_equals_select_path(gpu_lib, dt, shape):
         if thr == thr:
             sel = hp.select_threshold(d, acts, t)
             assert torch.equal(hp.densify(d, sel, D), fused)
+
+
+def test_encode_at_activation_store_batch_size(gpu_lib):
+    """The sample-collection / eval path encodes a whole model batch at once (training.py:141-145:
+    model_batch_size x seq_len = 512 x 128 = 65 536 positions): B*D = 2.4e9 elements, beyond 32-bit indexing.
+    Properties: rows are independent (a slice encoded alone gives the same rows, bit for bit); the training-mode
+    encode keeps exactly k*N entries; the collector sees every position."""
+    from matryoshka_transcoder_amd.activation_samples import ActivationSampleCollector
+    from matryoshka_transcoder_amd.transcoder import MatryoshkaTranscoder
+    N, A, D, k = 65536, 256, 36864, 32
+    cfg = dict(seed=2, prefix_sizes=[D // 4, D], act_size=A, top_k=k, top_k_aux=64, aux_penalty=1 / 32,
+               n_batches_to_dead=20, l1_coeff=0.0, dtype=torch.bfloat16, device="cuda")
+    tc = MatryoshkaTranscoder(cfg)
+    g = torch.Generator("cpu").manual_seed(9)
+    x = torch.randn(N, A, generator=g).to(torch.bfloat16).cuda()
+    with torch.no_grad():
+        tc.eval()
+        tc.threshold.fill_(0.35)
+        full = tc.encode(x)
+        assert full.shape == (N, D)
+        for lo in (0, 30000, N - 512):
+            assert torch.equal(tc.encode(x[lo:lo + 512].contiguous()), full[lo:lo + 512])
+        nnz_eval = int((full != 0).sum())
+        assert 0 < nnz_eval < N * D // 10
+        col = ActivationSampleCollector(16, 8, 0.1)
+        toks = torch.randint(0, 50000, (N // 128, 128), generator=g).cuda()
+        col.collect_batch_samples(full.reshape(N // 128, 128, D), toks, None)
+        assert col.total_samples_seen == nnz_eval
+        f = int(torch.argmax(col._count))
+        top = col.get_top_samples(f, k=1)[0]
+        assert top.activation_value == float(full[:, f].max()) and 0 <= top.position < 128
+        del full
+        tc.train()
+        feats = tc.encode(x)
+        assert int((feats != 0).sum()) == k * N
+        assert float(tc.threshold) > 0
