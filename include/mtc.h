@@ -292,6 +292,22 @@ int mtc_aux_fwd(const mtc_desc* d, const int32_t* row_ptr, const int32_t* col_id
                 float aux_penalty, void* g, void* g_aux, float* aux_rows, float* d_aux_vals,
                 void* stream);
 
+/* a9, dense (GEMM) form -- what the reference itself computes (sae.py:332-341: acts_aux @ W_dec[dead]).  With
+ * n_dead dead features the aux branch is four GEMMs over the compacted dead set ([B, n_dead] x [n_dead, A]); for
+ * every n_dead <= D these cost less on MFMA than gathering k_aux decoder rows per batch row (B*k_aux*A*s bytes).
+ * libmtc provides the selection and the fused elementwise parts, the caller runs the plain GEMMs (hipBLASLt):
+ *   mtc_aux_dense_fill : acts_aux[B][n_pad] (model dtype) = the row's top-k_aux dead activations in dead-list
+ *                        column order (threshold / tie quota from mtc_aux_select), zeros elsewhere and in the padding;
+ *   mtc_aux_residual   : given x_hat_aux = acts_aux @ W_dec[dead]: e = x_hat_aux - (x_target - x_hat) (residual not
+ *                        detached), aux_rows[b] = sum e^2, g_aux = (2 aux_penalty / (B A_t)) e, g += g_aux * std_row;
+ *   mtc_aux_mask       : d_acts_aux[i] = 0 where acts_aux[i] <= 0 (backward of the TopK scatter + ReLU). */
+int mtc_aux_dense_fill(const mtc_desc* d, const void* acts, const int32_t* dead_idx, const int32_t* n_dead_dev,
+                       const uint32_t* row_tau_bits, const uint32_t* row_tie_quota, int32_t n_pad, void* acts_aux,
+                       void* stream);
+int mtc_aux_residual(const mtc_desc* d, const void* x_hat_aux, const void* x_target, const void* x_hat, const void* std,
+                     float aux_penalty, void* g, void* g_aux, float* aux_rows, void* stream);
+int mtc_aux_mask(int32_t dtype, uint64_t n, const void* acts_aux, void* d_acts_aux, void* stream);
+
 /* a15 helpers: CSR <-> dense [B][D] in the model dtype (encode returns dense, decode takes it) */
 int mtc_densify(const mtc_desc* d, const int32_t* row_ptr, const int32_t* col_idx, const void* vals,
                 int32_t max_col, void* dense, void* stream);

@@ -150,7 +150,8 @@ __global__ __launch_bounds__(256) void aux_fwd_kernel(int B, int A_t, int unit_n
                                                       const void* __restrict__ x_target, const void* __restrict__ x_hat,
                                                       const void* __restrict__ std_p, void* __restrict__ g,
                                                       void* __restrict__ g_aux, float* __restrict__ aux_rows,
-                                                      float* __restrict__ d_aux_vals) {
+                                                      float* __restrict__ d_aux_vals,
+                                                      const void* __restrict__ x_hat_aux /* optional: reconstruction made elsewhere (dense GEMM path); then no gather */) {
     typedef DType<DT> D_;
     typedef typename D_::T T;
     RowCtx<DT, NC> rc;
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(256) void aux_fwd_kernel(int B, int A_t, int unit_n
     rc.nch = A_t >> 3;
     const int row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (row >= B) return;
-    const int e_begin = row_ptr[row], e_end = row_ptr[row + 1];
+    const int e_begin = x_hat_aux ? 0 : row_ptr[row], e_end = x_hat_aux ? 0 : row_ptr[row + 1];
     float acc[NC][8];
 #pragma unroll
     for (int c = 0; c < NC; ++c)
@@ -181,6 +182,7 @@ __global__ __launch_bounds__(256) void aux_fwd_kernel(int B, int A_t, int unit_n
             load8<DT>(x_target, off, t);
             load8<DT>(x_hat, off, h);
             if (g) load8<DT>(g, off, gg);
+            if (x_hat_aux) load8<DT>(x_hat_aux, off, acc[c]);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const float e = D_::rnd(acc[c][k]) - (t[k] - h[k]);
@@ -205,6 +207,51 @@ __global__ __launch_bounds__(256) void aux_fwd_kernel(int B, int A_t, int unit_n
             dot_run<DT, NC>(rc, W_dec, A_t, my_col, nb, gp, 0.f, d_aux_vals + e0);
         }
     }
+}
+
+// Dense form of the aux selection for the GEMM path: out[row][i] = acts[row][dead_idx[i]] if that entry is among the
+// row's top k_aux dead activations (same threshold / tie quota as aux_fill_kernel), else 0; columns i >= n_dead
+// (padding up to n_pad) are 0.  Wave per row.
+template <int DT>
+__global__ __launch_bounds__(256) void aux_dense_fill_kernel(const void* __restrict__ acts, int B, int D, int n_pad,
+                                                             const int32_t* __restrict__ dead_idx,
+                                                             const int32_t* __restrict__ n_dead_p,
+                                                             const uint32_t* __restrict__ row_tau,
+                                                             const uint32_t* __restrict__ row_quota, void* __restrict__ out) {
+    typedef typename DType<DT>::T T;
+    const int lane = threadIdx.x & 63;
+    const int row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (row >= B) return;
+    const int n_dead = min(*n_dead_p, n_pad);
+    const uint32_t tau = row_tau[row], quota = row_quota[row];
+    const size_t base = (size_t)row * D;
+    T* o = reinterpret_cast<T*>(out) + (size_t)row * n_pad;
+    uint32_t ties_seen = 0;
+    for (int i0 = 0; i0 < n_pad; i0 += 64) {
+        const int i = i0 + lane;
+        uint32_t k = 0; T raw = 0;
+        if (i < n_dead) { const int col = dead_idx[i]; raw = reinterpret_cast<const T*>(acts)[base + col]; k = key_of<DT>(acts, base + col); }
+        const bool ok = k != 0 && k <= 0x7f800000u;
+        const bool eq = ok && quota && k == tau;
+        bool sel = ok && k > tau;
+        const uint64_t eqb = __ballot(eq);
+        if (eqb) {
+            const uint32_t rank = ties_seen + (uint32_t)__popcll(eqb & ((1ull << lane) - 1ull));
+            if (eq && rank < quota) sel = true;
+            ties_seen += (uint32_t)__popcll(eqb);
+        }
+        if (i < n_pad) o[i] = sel ? raw : (T)0;
+    }
+}
+
+// d[i] = 0 where the aux activation is not selected (ReLU / TopK mask of the aux branch's backward)
+template <int DT>
+__global__ __launch_bounds__(256) void aux_mask_kernel(size_t n, const void* __restrict__ acts_aux, void* __restrict__ dvals) {
+    typedef typename DType<DT>::T T;
+    const T* a = reinterpret_cast<const T*>(acts_aux);
+    T* dv = reinterpret_cast<T*>(dvals);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        if (DType<DT>::ld(a + i) <= 0.f) dv[i] = (T)0;
 }
 
 }  // namespace mtc
@@ -260,6 +307,47 @@ extern "C" int mtc_aux_fwd(const mtc_desc* d, const int32_t* row_ptr, const int3
     MTC_REQUIRE(!d_aux_vals || g_aux, "mtc_aux_fwd: d_aux_vals needs g_aux");
     const float coef_aux = (float)(2.0 * (double)aux_penalty / ((double)d->B * (double)d->A_t));
     DISPATCH_NC(d->dtype, nc_for(d->A_t), aux_fwd_kernel, dim3((d->B + 3) / 4), dim3(256), as_stream(stream), d->B, d->A_t,
-                d->unit_norm, coef_aux, row_ptr, col_idx, vals, W_dec, x_target, x_hat, std, g, g_aux, aux_rows, d_aux_vals);
+                d->unit_norm, coef_aux, row_ptr, col_idx, vals, W_dec, x_target, x_hat, std, g, g_aux, aux_rows, d_aux_vals,
+                (const void*)nullptr);
     return check_launch("mtc_aux_fwd");
+}
+
+extern "C" int mtc_aux_dense_fill(const mtc_desc* d, const void* acts, const int32_t* dead_idx, const int32_t* n_dead_dev,
+                                  const uint32_t* row_tau_bits, const uint32_t* row_tie_quota, int32_t n_pad,
+                                  void* acts_aux, void* stream) {
+    if (check_desc(d, "mtc_aux_dense_fill")) return -1;
+    MTC_REQUIRE(acts && dead_idx && n_dead_dev && row_tau_bits && row_tie_quota && acts_aux, "mtc_aux_dense_fill: null pointer");
+    MTC_REQUIRE(n_pad > 0 && n_pad <= d->D + 8, "mtc_aux_dense_fill: n_pad must be in 1..D+8");
+    const dim3 grid((d->B + 3) / 4), block(256);
+    if (d->dtype == MTC_BF16)
+        hipLaunchKernelGGL(aux_dense_fill_kernel<MTC_BF16>, grid, block, 0, as_stream(stream), acts, d->B, d->D, n_pad, dead_idx,
+                           n_dead_dev, row_tau_bits, row_tie_quota, acts_aux);
+    else
+        hipLaunchKernelGGL(aux_dense_fill_kernel<MTC_F32>, grid, block, 0, as_stream(stream), acts, d->B, d->D, n_pad, dead_idx,
+                           n_dead_dev, row_tau_bits, row_tie_quota, acts_aux);
+    return check_launch("mtc_aux_dense_fill");
+}
+
+extern "C" int mtc_aux_residual(const mtc_desc* d, const void* x_hat_aux, const void* x_target, const void* x_hat,
+                                const void* std, float aux_penalty, void* g, void* g_aux, float* aux_rows, void* stream) {
+    if (check_desc(d, "mtc_aux_residual")) return -1;
+    MTC_REQUIRE(x_hat_aux && x_target && x_hat && aux_rows, "mtc_aux_residual: null pointer");
+    MTC_REQUIRE(!d->unit_norm || std, "mtc_aux_residual: unit_norm needs std");
+    const float coef_aux = (float)(2.0 * (double)aux_penalty / ((double)d->B * (double)d->A_t));
+    DISPATCH_NC(d->dtype, nc_for(d->A_t), aux_fwd_kernel, dim3((d->B + 3) / 4), dim3(256), as_stream(stream), d->B, d->A_t,
+                d->unit_norm, coef_aux, (const int32_t*)nullptr, (const int32_t*)nullptr, (const void*)nullptr,
+                (const void*)nullptr, x_target, x_hat, std, g, g_aux, aux_rows, (float*)nullptr, x_hat_aux);
+    return check_launch("mtc_aux_residual");
+}
+
+extern "C" int mtc_aux_mask(int32_t dtype, uint64_t n, const void* acts_aux, void* d_acts_aux, void* stream) {
+    MTC_REQUIRE(dtype == MTC_F32 || dtype == MTC_BF16, "mtc_aux_mask: bad dtype %d", dtype);
+    MTC_REQUIRE(acts_aux && d_acts_aux, "mtc_aux_mask: null pointer");
+    if (n == 0) return 0;
+    const unsigned blocks = (unsigned)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    if (dtype == MTC_BF16)
+        hipLaunchKernelGGL(aux_mask_kernel<MTC_BF16>, dim3(blocks), dim3(256), 0, as_stream(stream), (size_t)n, acts_aux, d_acts_aux);
+    else
+        hipLaunchKernelGGL(aux_mask_kernel<MTC_F32>, dim3(blocks), dim3(256), 0, as_stream(stream), (size_t)n, acts_aux, d_acts_aux);
+    return check_launch("mtc_aux_mask");
 }

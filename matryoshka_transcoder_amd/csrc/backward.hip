@@ -276,12 +276,18 @@ __global__ __launch_bounds__(256) void colsum_finish_kernel(int A, int slabs, co
 
 using namespace mtc;
 
-static int long_sort_blocks() { return 64; }
+// workgroups of the long-segment sort: each needs a B-int slot array in the workspace; up to 64 MiB of them
+// (1024 groups at B = 4096).  With the auxiliary loss active every dead feature is a long segment
+// (B * k_aux / n_dead entries), thousands per step.
+static int long_sort_blocks(const mtc_desc* d) {
+    const size_t fit = ((size_t)64 << 20) / ((size_t)d->B * sizeof(int32_t));
+    return (int)(fit < 64 ? 64 : fit > 1024 ? 1024 : fit);
+}
 
 extern "C" size_t mtc_csc_workspace_bytes(const mtc_desc* d) {
     if (!d) return 0;
     // counts[D] + cursor[D] + long_list[D] + tile sums / counter (pad) + long-segment row slots
-    return 3 * (size_t)d->D * sizeof(uint32_t) + 4096 + (size_t)long_sort_blocks() * d->B * sizeof(int32_t);
+    return 3 * (size_t)d->D * sizeof(uint32_t) + 4096 + (size_t)long_sort_blocks(d) * d->B * sizeof(int32_t);
 }
 
 extern "C" int mtc_build_csc(const mtc_desc* d, const int32_t* row_ptr, const int32_t* col_idx, void* workspace,
@@ -312,7 +318,7 @@ extern "C" int mtc_build_csc(const mtc_desc* d, const int32_t* row_ptr, const in
                        long_list, n_long);
     hipLaunchKernelGGL(csc_fill_kernel, rgrid, block, 0, s, d->B, row_ptr, col_idx, cursor, csc_row, csc_pos);
     hipLaunchKernelGGL(csc_sort_kernel, dim3((d->D + 3) / 4), block, 0, s, d->D, col_ptr, csc_row, csc_pos);
-    hipLaunchKernelGGL(csc_sort_long_kernel, dim3(long_sort_blocks()), block, 0, s, d->B, col_ptr, long_list, n_long, csc_row,
+    hipLaunchKernelGGL(csc_sort_long_kernel, dim3(long_sort_blocks(d)), block, 0, s, d->B, col_ptr, long_list, n_long, csc_row,
                        csc_pos, slots);
     return check_launch("mtc_build_csc");
 }

@@ -281,6 +281,57 @@ class HotPath:
                               float(aux_penalty), _p(g), _p(g_aux), _p(aux_rows), _p(d_aux), s), "mtc_aux_fwd")
         return sel, g_aux, aux_rows, d_aux
 
+    def aux_forward_dense(self, d, acts, dead_cnt, n_batches_to_dead: float, top_k_aux: int, aux_penalty: float, W_dec,
+                          x_target, x_hat, std, g, need_grad: bool):
+        """a9 in the reference's own dense form over the compacted dead set (sae.py:332-341), on MFMA: libmtc selects
+        (per-row top-k_aux, ties in dead-list order) and fuses the residual / loss / gradient elementwise part; the
+        [B, n_dead] x [n_dead, A_t] product is a plain library GEMM.  Reads n_dead back once to size the operands
+        (the reference synchronises at the same place, sae.py:331).  Returns (ctx dict, aux_rows[B]); g is updated
+        in place."""
+        dev = acts.device
+        lib, s = self.lib, _stream()
+        B = d.B
+        dead_idx = torch.empty(self.D, dtype=torch.int32, device=dev)
+        n_dead = torch.empty(1, dtype=torch.int32, device=dev)
+        check(lib.mtc_aux_dead_list(C.byref(d), _p(dead_cnt), float(n_batches_to_dead), _p(dead_idx), _p(n_dead), s),
+              "mtc_aux_dead_list")
+        row_cnt = torch.empty(B, dtype=torch.int32, device=dev)
+        row_tau = torch.empty(B, dtype=torch.int32, device=dev)
+        row_quota = torch.empty(B, dtype=torch.int32, device=dev)
+        check(lib.mtc_aux_select(C.byref(d), _p(acts), _p(dead_idx), _p(n_dead), int(top_k_aux), _p(row_cnt), _p(row_tau),
+                                 _p(row_quota), s), "mtc_aux_select")
+        n = int(n_dead.item())
+        n_pad = max((n + 7) // 8 * 8, 8)
+        idx = dead_idx[:n].long()
+        acts_aux = torch.empty(B, n_pad, dtype=self.dtype, device=dev)
+        check(lib.mtc_aux_dense_fill(C.byref(d), _p(acts), _p(dead_idx), _p(n_dead), _p(row_tau), _p(row_quota), n_pad,
+                                     _p(acts_aux), s), "mtc_aux_dense_fill")
+        W_dead = torch.zeros(n_pad, self.A_t, dtype=self.dtype, device=dev)
+        W_dead[:n] = W_dec.index_select(0, idx)
+        x_hat_aux = torch.matmul(acts_aux, W_dead)                     # hipBLASLt, fp32 accumulate, one rounding
+        g_aux = torch.empty(B, self.A_t, dtype=self.dtype, device=dev)
+        aux_rows = torch.empty(B, dtype=torch.float32, device=dev)
+        check(lib.mtc_aux_residual(C.byref(d), _p(x_hat_aux), _p(x_target), _p(x_hat), _p(std), float(aux_penalty), _p(g),
+                                   _p(g_aux), _p(aux_rows), s), "mtc_aux_residual")
+        ctx = dict(dense=True, idx=idx, n=n, acts_aux=acts_aux, W_dead=W_dead, g_aux=g_aux) if need_grad else dict(dense=True)
+        return ctx, aux_rows
+
+    def aux_backward_dense(self, ctx, x_norm, g_loss, grads):
+        """Gradients of the aux branch, accumulated into the dense gradients (model dtype): three GEMMs over the dead set
+        + the TopK / ReLU mask; rows land at the dead features' positions (unique indices: deterministic)."""
+        dW_dec, dW_encT, db_enc, db_dec = grads
+        n, idx, acts_aux, g_aux = ctx["n"], ctx["idx"], ctx["acts_aux"], ctx["g_aux"]
+        if n == 0:
+            return grads
+        if g_loss is not None:
+            g_aux = (g_aux.float() * g_loss.reshape(()).float()).to(self.dtype)
+        d_acts = torch.matmul(g_aux, ctx["W_dead"].t())                 # [B, n_pad]
+        check(self.lib.mtc_aux_mask(self.code, d_acts.numel(), _p(acts_aux), _p(d_acts), _stream()), "mtc_aux_mask")
+        dW_dec.index_add_(0, idx, torch.matmul(acts_aux.t(), g_aux)[:n])
+        dW_encT.index_add_(0, idx, torch.matmul(d_acts.t(), x_norm)[:n])
+        db_enc.index_add_(0, idx, d_acts.sum(0)[:n])
+        return grads
+
     # ------------------------------------------------------------------ a12 / a13
     def unitnorm_project(self, W_dec, grad):
         _need(W_dec, "W_dec", self.dtype, (self.D, self.A_t))

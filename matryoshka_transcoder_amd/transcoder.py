@@ -242,6 +242,10 @@ class MatryoshkaTranscoder(nn.Module):
     def _run_aux(self, hp, d, acts, sel, W_dec, x_target, x_hat, g, need_grad, l1_term):
         cfg = self.config
         std = self.x_std.reshape(-1).contiguous() if hp.unit_norm else None
+        if cfg.get("aux_mode", "gemm") == "gemm":
+            # the reference's own dense form over the dead set, on MFMA (cheaper than k_aux row gathers per batch row)
+            return hp.aux_forward_dense(d, acts, self._cnt, float(cfg["n_batches_to_dead"]), int(cfg["top_k_aux"]),
+                                        float(cfg["aux_penalty"]), W_dec, x_target, x_hat, std, g, need_grad)
         asel, g_aux, aux_rows, d_aux = hp.aux_forward(
             d, acts, self._cnt, float(cfg["n_batches_to_dead"]), int(cfg["top_k_aux"]),
             float(cfg["aux_penalty"]), W_dec, x_target, x_hat, std, g, need_grad)
@@ -251,6 +255,8 @@ class MatryoshkaTranscoder(nn.Module):
 
     def _run_aux_backward(self, hp, res, g_loss, grads):
         a = res.aux
+        if a.get("dense"):
+            return hp.aux_backward_dense(a, res.x_norm, g_loss, grads)
         return hp.backward(res.desc, a["sel"], a["g_aux"], a["d_vals"], res.x_norm, g_loss, grads=grads,
                            with_colsum=False)
 

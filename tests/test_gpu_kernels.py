@@ -235,14 +235,16 @@ def test_unitnorm_adam_against_oracle(dt, gpu_lib):
     _close(pd, pr, rt, at, "flat p"); _close(mdv, mr, rt * 2, at, "flat m"); _close(vdv, vr, rt * 2, at * 1e-2, "flat v")
 
 
+@pytest.mark.parametrize("aux_mode", ["gemm", "sparse"])
 @pytest.mark.parametrize("name", ["fp32_aux", "fp32_aux_unit", "bf16_aux"])
-def test_aux_path_against_oracle(name, gpu_lib):
-    """a9: dead list, per-row top-k_aux, aux reconstruction / loss, and every gradient with aux active."""
+def test_aux_path_against_oracle(name, aux_mode, gpu_lib):
+    """a9: dead list, per-row top-k_aux, aux reconstruction / loss, and every gradient with aux active -- in the dense
+    form over the dead set (GEMMs; the single-GPU default) and in the row-gather form (what the sharded model runs)."""
     from matryoshka_transcoder_amd.transcoder import MatryoshkaTranscoder
     fx, cfg = load_golden(name)
     dt = cfg["dtype"]
     f32 = dt == torch.float32
-    m = MatryoshkaTranscoder(dict(cfg, device=DEV))
+    m = MatryoshkaTranscoder(dict(cfg, device=DEV, aux_mode=aux_mode))
     m.load_state_dict({k: v.to(DEV) for k, v in fx["init"].items()})
     m.num_batches_not_active = fx["cnt0"].clone().to(DEV)
     s0 = fx["steps"][0]
@@ -254,13 +256,20 @@ def test_aux_path_against_oracle(name, gpu_lib):
     acts_gpu = m.hot_path().encode(res.desc, res.x_norm, m.W_enc.t(), m.b_enc).cpu()
     o, new, inter = R.forward(params, {"num_batches_not_active": fx["cnt0"].clone()}, xs, xt, cfg, acts_override=acts_gpu)
     aux = inter["aux"]
-    asel = res.aux["sel"]
-    rp = asel.row_ptr.cpu().long()
-    n = int(rp[-1])
-    assert n == aux["rows"].numel()
     B, D = xs.shape[0], cfg["prefix_sizes"][-1]
-    rows = torch.repeat_interleave(torch.arange(B), rp[1:] - rp[:-1])
-    got = set((rows * D + asel.col_idx.cpu()[:n].long()).tolist())
+    if aux_mode == "gemm":
+        a = res.aux
+        assert a["dense"] and a["acts_aux"].shape[1] % 8 == 0 and not bool(a["acts_aux"][:, a["n"]:].any())
+        nzr, nzc = torch.nonzero(a["acts_aux"][:, :a["n"]].cpu(), as_tuple=True)
+        got = set((nzr * D + a["idx"].cpu()[nzc]).tolist())
+        assert len(got) == aux["rows"].numel()
+    else:
+        asel = res.aux["sel"]
+        rp = asel.row_ptr.cpu().long()
+        n = int(rp[-1])
+        assert n == aux["rows"].numel()
+        rows = torch.repeat_interleave(torch.arange(B), rp[1:] - rp[:-1])
+        got = set((rows * D + asel.col_idx.cpu()[:n].long()).tolist())
     want = set((aux["rows"] * D + aux["cols"]).tolist())
     assert got == want, "aux selection differs from the oracle's"
     rt, at = (1e-4, 1e-7) if f32 else (2e-2, 1e-4)
