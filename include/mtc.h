@@ -266,6 +266,22 @@ int mtc_fused_backward_adam_enc(const mtc_desc* d, const int32_t* col_ptr, const
                                 const float* scale, void* W_encT, void* exp_avg, void* exp_avg_sq,
                                 void* b_enc, void* b_exp_avg, void* b_exp_avg_sq,
                                 const mtc_adam_hyper* h_host, void* stream);
+
+/* The same two launches with a dense extra contribution for some rows (the aux branch's GEMM results over the dead
+ * features, see mtc_aux_dense_fill): extra_row[D] holds -1 or the row of extra_rows [.][A] (model dtype) to add to
+ * feature j's rounded sparse gradient -- rounded again, as `grad[dead] += ...` on a materialised gradient would be --
+ * before projection / Adam; extra_bias[.] likewise for the b_enc element.  No counterpart entry in the reference: it
+ * is autograd's accumulation of the two branches' gradients (sae.py:245 loss = l2 + l1 + aux). */
+int mtc_fused_backward_adam_dec_extra(const mtc_desc* d, const int32_t* col_ptr, const int32_t* csc_row,
+                                      const int32_t* csc_pos, const void* vals, const void* g, const float* scale,
+                                      void* W_dec, void* exp_avg, void* exp_avg_sq, const mtc_adam_hyper* h,
+                                      float* d_vals_out, float l1_term, const int32_t* extra_row, const void* extra_rows,
+                                      void* stream);
+int mtc_fused_backward_adam_enc_extra(const mtc_desc* d, const int32_t* col_ptr, const int32_t* csc_row,
+                                      const int32_t* csc_pos, const float* d_vals, const void* x_norm, const float* scale,
+                                      void* W_encT, void* exp_avg, void* exp_avg_sq, void* b_enc, void* b_exp_avg,
+                                      void* b_exp_avg_sq, const mtc_adam_hyper* h, const int32_t* extra_row,
+                                      const void* extra_rows, const void* extra_bias, void* stream);
 /* projection only (the reference method called on its own, sae.py:155-163) */
 int mtc_unitnorm_project(const mtc_desc* d, void* W_dec, void* grad, void* stream);
 

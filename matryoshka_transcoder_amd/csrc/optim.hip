@@ -124,13 +124,18 @@ __global__ __launch_bounds__(256) void unitnorm_rows_kernel(int D, int A, void* 
 #endif
 //   WITH_DOT = 1 (decoder rows only): the same gather of g also produces d a_bj = g_b . W_dec[j] + l1_term
 //   for the feature's entries (d_vals_out[csc_pos]), which replaces the decode kernel's second sweep.
-template <int DT, int COEF_DT, int NC, int PROJECT, int WITH_DOT>
+//   EXTRA = 1: a second, dense gradient contribution for some rows (the auxiliary branch's GEMM results over the dead
+//   features): extra_row[j] >= 0 names the row of `extra` [.][A] (and the element of `extra_bias`) that is added to the
+//   rounded sparse gradient of feature j, with the rounding a dense `grad += ...` would make.  EXTRA = 0 compiles to
+//   the kernel without these operands.
+template <int DT, int COEF_DT, int NC, int PROJECT, int WITH_DOT, int EXTRA>
 __global__ __launch_bounds__(256, (DT == MTC_BF16 ? (NC <= 5 ? MTC_FUSED_WAVES : 2) : (NC <= 2 ? 4 : NC <= 5 ? 2 : 1))) void fused_grad_adam_kernel(
     int D, int A, const int32_t* __restrict__ col_ptr, const int32_t* __restrict__ csc_row,
     const int32_t* __restrict__ csc_pos, const void* __restrict__ coef, const void* __restrict__ src,
     const float* __restrict__ scale_p, void* __restrict__ W, void* __restrict__ m, void* __restrict__ v,
     void* __restrict__ bias, void* __restrict__ m_b, void* __restrict__ v_b, AdamK k, float* __restrict__ d_vals_out,
-    float l1_term) {
+    float l1_term, const int32_t* __restrict__ extra_row, const void* __restrict__ extra,
+    const void* __restrict__ extra_bias) {
     typedef DType<DT> D_;
     typedef typename D_::T T;
     RowCtx<DT, NC> rc;
@@ -175,6 +180,22 @@ __global__ __launch_bounds__(256, (DT == MTC_BF16 ? (NC <= 5 ? MTC_FUSED_WAVES :
             for (int q = 0; q < 8; ++q) acc[c][q] *= scale;
             gr[c] = pack_raw<DT>(acc[c]);
         }
+    int xr = -1;
+    if constexpr (EXTRA != 0) {
+        xr = __builtin_amdgcn_readfirstlane(extra_row[j]);
+        if (xr >= 0) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                if (rc.valid(c)) {
+                    float a[8], b[8];
+                    unpack(gr[c], a);
+                    load8<DT>(extra, (size_t)xr * A + rc.off(c), b);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) a[q] = D_::rnd(a[q] + b[q]);
+                    gr[c] = pack_raw<DT>(a);
+                }
+        }
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int c = 0; c < NC; ++c)
@@ -227,7 +248,10 @@ __global__ __launch_bounds__(256, (DT == MTC_BF16 ? (NC <= 5 ? MTC_FUSED_WAVES :
         if (lane == 0) {
             T* bp = reinterpret_cast<T*>(bias) + j; T* mp = reinterpret_cast<T*>(m_b) + j; T* vp = reinterpret_cast<T*>(v_b) + j;
             float b = D_::ld(bp), mb = D_::ld(mp), vb = D_::ld(vp);
-            adam_elem<DT>(b, D_::rnd(scale * csum), mb, vb, k);
+            float gb = D_::rnd(scale * csum);
+            if constexpr (EXTRA != 0)
+                if (xr >= 0 && extra_bias) gb = D_::rnd(gb + D_::ld(reinterpret_cast<const T*>(extra_bias) + xr));
+            adam_elem<DT>(b, gb, mb, vb, k);
             D_::st(bp, b); D_::st(mp, mb); D_::st(vp, vb);
         }
     }
@@ -304,24 +328,37 @@ extern "C" int mtc_adam_flat(int32_t dtype, size_t n, void* p, const void* grad,
     return check_launch("mtc_adam_flat");
 }
 
-#define LAUNCH_FUSED(DTV, COEF, PROJ, DOT)                                                                                        \
+#define LAUNCH_FUSED_NC(DTV, COEF, PROJ, DOT, EX, NCV)                                                                          \
+    hipLaunchKernelGGL((fused_grad_adam_kernel<DTV, COEF, NCV, PROJ, DOT, EX>), grid, block, 0, s, d->D, A, col_ptr, csc_row,      \
+                       csc_pos, coef, src, scale, W, m, v, bias, m_b, v_b, k, dv_out, l1_term, extra_row, extra, extra_bias)
+#define LAUNCH_FUSED(DTV, COEF, PROJ, DOT, EX)                                                                                    \
     do {                                                                                                                     \
         const int nc_ = nc_for(A);                                                                                           \
         const dim3 grid((d->D + 3) / 4), block(256);                                                                         \
-        if (nc_ <= 1) hipLaunchKernelGGL((fused_grad_adam_kernel<DTV, COEF, 1, PROJ, DOT>), grid, block, 0, s, d->D, A, col_ptr, csc_row, csc_pos, coef, src, scale, W, m, v, bias, m_b, v_b, k, dv_out, l1_term); \
-        else if (nc_ <= 2) hipLaunchKernelGGL((fused_grad_adam_kernel<DTV, COEF, 2, PROJ, DOT>), grid, block, 0, s, d->D, A, col_ptr, csc_row, csc_pos, coef, src, scale, W, m, v, bias, m_b, v_b, k, dv_out, l1_term); \
-        else if (nc_ <= 3) hipLaunchKernelGGL((fused_grad_adam_kernel<DTV, COEF, 3, PROJ, DOT>), grid, block, 0, s, d->D, A, col_ptr, csc_row, csc_pos, coef, src, scale, W, m, v, bias, m_b, v_b, k, dv_out, l1_term); \
-        else if (nc_ <= 5) hipLaunchKernelGGL((fused_grad_adam_kernel<DTV, COEF, 5, PROJ, DOT>), grid, block, 0, s, d->D, A, col_ptr, csc_row, csc_pos, coef, src, scale, W, m, v, bias, m_b, v_b, k, dv_out, l1_term); \
-        else if (nc_ <= 7) hipLaunchKernelGGL((fused_grad_adam_kernel<DTV, COEF, 7, PROJ, DOT>), grid, block, 0, s, d->D, A, col_ptr, csc_row, csc_pos, coef, src, scale, W, m, v, bias, m_b, v_b, k, dv_out, l1_term); \
-        else if (nc_ <= 9) hipLaunchKernelGGL((fused_grad_adam_kernel<DTV, COEF, 9, PROJ, DOT>), grid, block, 0, s, d->D, A, col_ptr, csc_row, csc_pos, coef, src, scale, W, m, v, bias, m_b, v_b, k, dv_out, l1_term); \
-        else hipLaunchKernelGGL((fused_grad_adam_kernel<DTV, COEF, 16, PROJ, DOT>), grid, block, 0, s, d->D, A, col_ptr, csc_row, csc_pos, coef, src, scale, W, m, v, bias, m_b, v_b, k, dv_out, l1_term); \
+        if (nc_ <= 1) LAUNCH_FUSED_NC(DTV, COEF, PROJ, DOT, EX, 1);                                                          \
+        else if (nc_ <= 2) LAUNCH_FUSED_NC(DTV, COEF, PROJ, DOT, EX, 2);                                                     \
+        else if (nc_ <= 3) LAUNCH_FUSED_NC(DTV, COEF, PROJ, DOT, EX, 3);                                                     \
+        else if (nc_ <= 5) LAUNCH_FUSED_NC(DTV, COEF, PROJ, DOT, EX, 5);                                                     \
+        else if (nc_ <= 7) LAUNCH_FUSED_NC(DTV, COEF, PROJ, DOT, EX, 7);                                                     \
+        else if (nc_ <= 9) LAUNCH_FUSED_NC(DTV, COEF, PROJ, DOT, EX, 9);                                                     \
+        else LAUNCH_FUSED_NC(DTV, COEF, PROJ, DOT, EX, 16);                                                                  \
     } while (0)
 
 extern "C" int mtc_fused_backward_adam_dec(const mtc_desc* d, const int32_t* col_ptr, const int32_t* csc_row,
                                            const int32_t* csc_pos, const void* vals, const void* g, const float* scale,
                                            void* W_dec, void* exp_avg, void* exp_avg_sq, const mtc_adam_hyper* h_host,
                                            float* d_vals_out, float l1_term, void* stream) {
+    return mtc_fused_backward_adam_dec_extra(d, col_ptr, csc_row, csc_pos, vals, g, scale, W_dec, exp_avg, exp_avg_sq, h_host,
+                                             d_vals_out, l1_term, nullptr, nullptr, stream);
+}
+
+extern "C" int mtc_fused_backward_adam_dec_extra(const mtc_desc* d, const int32_t* col_ptr, const int32_t* csc_row,
+                                                 const int32_t* csc_pos, const void* vals, const void* g, const float* scale,
+                                                 void* W_dec, void* exp_avg, void* exp_avg_sq, const mtc_adam_hyper* h_host,
+                                                 float* d_vals_out, float l1_term, const int32_t* extra_row,
+                                                 const void* extra_rows, void* stream) {
     if (check_desc(d, "mtc_fused_backward_adam_dec")) return -1;
+    MTC_REQUIRE((extra_row == nullptr) == (extra_rows == nullptr), "mtc_fused_backward_adam_dec: extra_row and extra_rows go together");
     MTC_REQUIRE(col_ptr && csc_row && csc_pos && vals && g && W_dec && exp_avg && exp_avg_sq && h_host,
                 "mtc_fused_backward_adam_dec: null pointer");
     MTC_REQUIRE(h_host->step >= 1, "mtc_fused_backward_adam_dec: step is 1-based");
@@ -331,12 +368,17 @@ extern "C" int mtc_fused_backward_adam_dec(const mtc_desc* d, const int32_t* col
     const void* coef = vals; const void* src = g;
     void* W = W_dec; void* m = exp_avg; void* v = exp_avg_sq; void* bias = nullptr; void* m_b = nullptr; void* v_b = nullptr;
     float* dv_out = d_vals_out;
-    if (dv_out) {
-        if (d->dtype == MTC_BF16) LAUNCH_FUSED(MTC_BF16, MTC_BF16, 1, 1);
-        else LAUNCH_FUSED(MTC_F32, MTC_F32, 1, 1);
+    const void* extra = extra_rows; const void* extra_bias = nullptr;
+    if (extra_row) {
+        MTC_REQUIRE(dv_out, "mtc_fused_backward_adam_dec: the extra-row form also produces d_vals (pass d_vals_out)");
+        if (d->dtype == MTC_BF16) LAUNCH_FUSED(MTC_BF16, MTC_BF16, 1, 1, 1);
+        else LAUNCH_FUSED(MTC_F32, MTC_F32, 1, 1, 1);
+    } else if (dv_out) {
+        if (d->dtype == MTC_BF16) LAUNCH_FUSED(MTC_BF16, MTC_BF16, 1, 1, 0);
+        else LAUNCH_FUSED(MTC_F32, MTC_F32, 1, 1, 0);
     } else {
-        if (d->dtype == MTC_BF16) LAUNCH_FUSED(MTC_BF16, MTC_BF16, 1, 0);
-        else LAUNCH_FUSED(MTC_F32, MTC_F32, 1, 0);
+        if (d->dtype == MTC_BF16) LAUNCH_FUSED(MTC_BF16, MTC_BF16, 1, 0, 0);
+        else LAUNCH_FUSED(MTC_F32, MTC_F32, 1, 0, 0);
     }
     return check_launch("mtc_fused_backward_adam_dec");
 }
@@ -345,7 +387,18 @@ extern "C" int mtc_fused_backward_adam_enc(const mtc_desc* d, const int32_t* col
                                            const int32_t* csc_pos, const float* d_vals, const void* x_norm, const float* scale,
                                            void* W_encT, void* exp_avg, void* exp_avg_sq, void* b_enc, void* b_exp_avg,
                                            void* b_exp_avg_sq, const mtc_adam_hyper* h_host, void* stream) {
+    return mtc_fused_backward_adam_enc_extra(d, col_ptr, csc_row, csc_pos, d_vals, x_norm, scale, W_encT, exp_avg, exp_avg_sq,
+                                             b_enc, b_exp_avg, b_exp_avg_sq, h_host, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int mtc_fused_backward_adam_enc_extra(const mtc_desc* d, const int32_t* col_ptr, const int32_t* csc_row,
+                                                 const int32_t* csc_pos, const float* d_vals, const void* x_norm,
+                                                 const float* scale, void* W_encT, void* exp_avg, void* exp_avg_sq, void* b_enc,
+                                                 void* b_exp_avg, void* b_exp_avg_sq, const mtc_adam_hyper* h_host,
+                                                 const int32_t* extra_row, const void* extra_rows, const void* extra_bias_in,
+                                                 void* stream) {
     if (check_desc(d, "mtc_fused_backward_adam_enc")) return -1;
+    MTC_REQUIRE((extra_row == nullptr) == (extra_rows == nullptr), "mtc_fused_backward_adam_enc: extra_row and extra_rows go together");
     MTC_REQUIRE(col_ptr && csc_row && csc_pos && d_vals && x_norm && W_encT && exp_avg && exp_avg_sq && b_enc && b_exp_avg &&
                 b_exp_avg_sq && h_host, "mtc_fused_backward_adam_enc: null pointer");
     MTC_REQUIRE(h_host->step >= 1, "mtc_fused_backward_adam_enc: step is 1-based");
@@ -355,7 +408,13 @@ extern "C" int mtc_fused_backward_adam_enc(const mtc_desc* d, const int32_t* col
     const void* coef = d_vals; const void* src = x_norm;
     void* W = W_encT; void* m = exp_avg; void* v = exp_avg_sq; void* bias = b_enc; void* m_b = b_exp_avg; void* v_b = b_exp_avg_sq;
     float* dv_out = nullptr; const float l1_term = 0.f;
-    if (d->dtype == MTC_BF16) LAUNCH_FUSED(MTC_BF16, MTC_F32, 0, 0);
-    else LAUNCH_FUSED(MTC_F32, MTC_F32, 0, 0);
+    const void* extra = extra_rows; const void* extra_bias = extra_bias_in;
+    if (extra_row) {
+        if (d->dtype == MTC_BF16) LAUNCH_FUSED(MTC_BF16, MTC_F32, 0, 0, 1);
+        else LAUNCH_FUSED(MTC_F32, MTC_F32, 0, 0, 1);
+    } else {
+        if (d->dtype == MTC_BF16) LAUNCH_FUSED(MTC_BF16, MTC_F32, 0, 0, 0);
+        else LAUNCH_FUSED(MTC_F32, MTC_F32, 0, 0, 0);
+    }
     return check_launch("mtc_fused_backward_adam_enc");
 }

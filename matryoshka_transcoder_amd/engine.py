@@ -301,7 +301,9 @@ class HotPath:
         check(lib.mtc_aux_select(C.byref(d), _p(acts), _p(dead_idx), _p(n_dead), int(top_k_aux), _p(row_cnt), _p(row_tau),
                                  _p(row_quota), s), "mtc_aux_select")
         n = int(n_dead.item())
-        n_pad = max((n + 7) // 8 * 8, 8)
+        if n == 0:
+            return None, None            # no dead feature after all (sae.py:331: the branch returns a zero)
+        n_pad = (n + 7) // 8 * 8
         idx = dead_idx[:n].long()
         acts_aux = torch.empty(B, n_pad, dtype=self.dtype, device=dev)
         check(lib.mtc_aux_dense_fill(C.byref(d), _p(acts), _p(dead_idx), _p(n_dead), _p(row_tau), _p(row_quota), n_pad,
@@ -313,23 +315,32 @@ class HotPath:
         aux_rows = torch.empty(B, dtype=torch.float32, device=dev)
         check(lib.mtc_aux_residual(C.byref(d), _p(x_hat_aux), _p(x_target), _p(x_hat), _p(std), float(aux_penalty), _p(g),
                                    _p(g_aux), _p(aux_rows), s), "mtc_aux_residual")
-        ctx = dict(dense=True, idx=idx, n=n, acts_aux=acts_aux, W_dead=W_dead, g_aux=g_aux) if need_grad else dict(dense=True)
+        ctx = dict(dense=True, n=n)
+        if need_grad:
+            ctx.update(idx=idx, acts_aux=acts_aux, W_dead=W_dead, g_aux=g_aux)
         return ctx, aux_rows
 
-    def aux_backward_dense(self, ctx, x_norm, g_loss, grads):
-        """Gradients of the aux branch, accumulated into the dense gradients (model dtype): three GEMMs over the dead set
-        + the TopK / ReLU mask; rows land at the dead features' positions (unique indices: deterministic)."""
-        dW_dec, dW_encT, db_enc, db_dec = grads
-        n, idx, acts_aux, g_aux = ctx["n"], ctx["idx"], ctx["acts_aux"], ctx["g_aux"]
-        if n == 0:
-            return grads
+    def aux_extra_rows(self, ctx, x_norm, g_loss=None):
+        """Gradient rows of the aux branch over the dead set (model dtype, one rounding per GEMM like the reference's
+        matmul backward): (E_dec [n_pad, A_t], E_enc [n_pad, A_s], e_b [n_pad]); rows >= n are zero."""
+        acts_aux, g_aux = ctx["acts_aux"], ctx["g_aux"]
         if g_loss is not None:
             g_aux = (g_aux.float() * g_loss.reshape(()).float()).to(self.dtype)
         d_acts = torch.matmul(g_aux, ctx["W_dead"].t())                 # [B, n_pad]
         check(self.lib.mtc_aux_mask(self.code, d_acts.numel(), _p(acts_aux), _p(d_acts), _stream()), "mtc_aux_mask")
-        dW_dec.index_add_(0, idx, torch.matmul(acts_aux.t(), g_aux)[:n])
-        dW_encT.index_add_(0, idx, torch.matmul(d_acts.t(), x_norm)[:n])
-        db_enc.index_add_(0, idx, d_acts.sum(0)[:n])
+        return torch.matmul(acts_aux.t(), g_aux), torch.matmul(d_acts.t(), x_norm), d_acts.sum(0)
+
+    def aux_backward_dense(self, ctx, x_norm, g_loss, grads):
+        """Gradients of the aux branch accumulated into materialised dense gradients (the autograd path): rows land at
+        the dead features' positions (unique indices: deterministic)."""
+        dW_dec, dW_encT, db_enc, db_dec = grads
+        n, idx = ctx["n"], ctx["idx"]
+        if n == 0:
+            return grads
+        E_dec, E_enc, e_b = self.aux_extra_rows(ctx, x_norm, g_loss)
+        dW_dec.index_add_(0, idx, E_dec[:n])
+        dW_encT.index_add_(0, idx, E_enc[:n])
+        db_enc.index_add_(0, idx, e_b[:n])
         return grads
 
     # ------------------------------------------------------------------ a12 / a13
@@ -353,9 +364,10 @@ class HotPath:
               "mtc_adam_flat")
 
     def fused_backward_adam(self, d, sel: Selection, g, d_vals, x_norm, scale, W_dec, st_dec, W_encT, st_enc, b_enc,
-                            st_benc, h_dec: AdamHyper, h_enc: AdamHyper, h_benc: AdamHyper, l1_term: float = 0.0):
+                            st_benc, h_dec: AdamHyper, h_enc: AdamHyper, h_benc: AdamHyper, l1_term: float = 0.0, extra=None):
         """a11 + a12 + a13 in two launches; st_* = (exp_avg, exp_avg_sq) in the storage layout of the parameter.
-        d_vals=None: the decoder launch also produces d a_bj (the forward skipped its second sweep)."""
+        d_vals=None: the decoder launch also produces d a_bj (the forward skipped its second sweep).
+        extra = (row_map int32[D], E_dec, E_enc, e_b): dense extra gradient rows (aux branch) added per feature."""
         dv_out = None
         if d_vals is None:
             d_vals = dv_out = torch.empty(max(sel.col_idx.numel(), 1), dtype=torch.float32, device=g.device)
@@ -368,12 +380,28 @@ class HotPath:
                           (st_benc[1], "exp_avg_sq(b_enc)", (self.D,))):
             _need(t, n, self.dtype, shp)
         s = _stream()
+        if h_enc.step != h_benc.step or h_enc.lr != h_benc.lr:
+            raise _lib.MtcError("W_enc and b_enc must share one Adam step count / lr for the fused update")
+        if extra is not None:
+            row_map, E_dec, E_enc, e_b = extra
+            _need(row_map, "extra row map", torch.int32, (self.D,))
+            _need(E_dec, "extra decoder rows", self.dtype); _need(E_enc, "extra encoder rows", self.dtype)
+            _need(e_b, "extra bias elements", self.dtype)
+            if dv_out is None or E_dec.shape[1] != self.A_t or E_enc.shape[1] != self.A_s or e_b.numel() != E_enc.shape[0]:
+                raise _lib.MtcError("extra gradient rows: pass d_vals=None and [n, A_t] / [n, A_s] / [n] operands")
+            check(self.lib.mtc_fused_backward_adam_dec_extra(
+                C.byref(d), _p(sel.col_ptr), _p(sel.csc_row), _p(sel.csc_pos), _p(sel.vals), _p(g), _p(scale), _p(W_dec),
+                _p(st_dec[0]), _p(st_dec[1]), C.byref(h_dec), _p(dv_out), float(l1_term), _p(row_map), _p(E_dec), s),
+                "mtc_fused_backward_adam_dec_extra")
+            check(self.lib.mtc_fused_backward_adam_enc_extra(
+                C.byref(d), _p(sel.col_ptr), _p(sel.csc_row), _p(sel.csc_pos), _p(d_vals), _p(x_norm), _p(scale), _p(W_encT),
+                _p(st_enc[0]), _p(st_enc[1]), _p(b_enc), _p(st_benc[0]), _p(st_benc[1]), C.byref(h_enc), _p(row_map),
+                _p(E_enc), _p(e_b), s), "mtc_fused_backward_adam_enc_extra")
+            return
         check(self.lib.mtc_fused_backward_adam_dec(C.byref(d), _p(sel.col_ptr), _p(sel.csc_row), _p(sel.csc_pos), _p(sel.vals),
                                                    _p(g), _p(scale), _p(W_dec), _p(st_dec[0]), _p(st_dec[1]), C.byref(h_dec),
                                                    _p(dv_out), float(l1_term), s),
               "mtc_fused_backward_adam_dec")
-        if h_enc.step != h_benc.step or h_enc.lr != h_benc.lr:
-            raise _lib.MtcError("W_enc and b_enc must share one Adam step count / lr for the fused update")
         check(self.lib.mtc_fused_backward_adam_enc(C.byref(d), _p(sel.col_ptr), _p(sel.csc_row), _p(sel.csc_pos), _p(d_vals),
                                                    _p(x_norm), _p(scale), _p(W_encT), _p(st_enc[0]), _p(st_enc[1]), _p(b_enc),
                                                    _p(st_benc[0]), _p(st_benc[1]), C.byref(h_enc), s),

@@ -71,8 +71,9 @@ class FusedAdam(torch.optim.Optimizer):
     def train_step(self, x_source, x_target):
         """One whole training step (training.py:92,172-179) without materialising gradients: forward chain,
         then per parameter row {k-sparse gradient -> unit-norm projection -> Adam} in one kernel.  Returns the
-        reference's output dict (no autograd graph).  While the auxiliary loss is active the step falls back
-        to dense gradients + `step(project=True)`, because aux contributions must be summed into them first."""
+        reference's output dict (no autograd graph).  While the auxiliary loss is active its gradient rows over the
+        dead features (GEMM results) are added inside the same kernels; only the row-gather form of the aux branch
+        (sharded model) still goes through dense gradients + `step(project=True)`."""
         tc = self.transcoder
         if not tc.training:
             raise _lib.MtcError("train_step() needs the transcoder in training mode")
@@ -84,7 +85,14 @@ class FusedAdam(torch.optim.Optimizer):
         tc._last_res = res
         out = tc._output_dict(res, x_target)
         hp = tc.hot_path()
-        if res.aux is not None:
+        extra = None
+        if res.aux is not None and res.aux.get("dense") and res.d_vals is None:
+            # dense aux branch: its gradient rows over the dead set (three GEMMs) ride into the fused kernels
+            a = res.aux
+            row_map = torch.full((tc.total_dict_size,), -1, dtype=torch.int32, device=res.g.device)
+            row_map[a["idx"]] = torch.arange(a["n"], dtype=torch.int32, device=res.g.device)
+            extra = (row_map,) + tuple(t.contiguous() for t in hp.aux_extra_rows(a, res.x_norm))
+        elif res.aux is not None:
             dW_dec, dW_encT, db_enc, db_dec = tc._run_backward(res, None)
             tc.W_dec.grad, tc.W_enc.grad, tc.b_enc.grad, tc.b_dec.grad = dW_dec, dW_encT.t(), db_enc, db_dec
             self.step(project=True)
@@ -106,7 +114,7 @@ class FusedAdam(torch.optim.Optimizer):
         hp.fused_backward_adam(res.desc, res.sel, res.g, res.d_vals, res.x_norm, None, tc.W_dec.data,
                                (sd["exp_avg"], sd["exp_avg_sq"]), W_encT.data, (m_e, v_e), tc.b_enc.data,
                                (sb["exp_avg"], sb["exp_avg_sq"]), hy["W_dec"], hy["W_enc"], hy["b_enc"],
-                               l1_term=float(tc.config["l1_coeff"]) / (res.desc.B * tc.total_dict_size))
+                               l1_term=float(tc.config["l1_coeff"]) / (res.desc.B * tc.total_dict_size), extra=extra)
         db_dec = hp.colsum(res.desc, res.g)
         hp.adam_flat(tc.b_dec.data, db_dec, sbd["exp_avg"], sbd["exp_avg_sq"], hy["b_dec"])
         return out

@@ -186,6 +186,10 @@ class MatryoshkaTranscoder(nn.Module):
         the (synchronising) check repeated.  The reference synchronises on every call (sae.py:331)."""
         if self._dead_check_in > 0:
             return False
+        if getattr(self, "_aux_n_dead", 0) > 0:
+            # dead features existed one forward ago: skip the read-back, the dead list built next settles it
+            # (it reads its own count back, and an empty list switches the branch off again)
+            return True
         n_dead_at = float(self.config["n_batches_to_dead"])
         mx = float(self._cnt.max().item())
         if mx >= n_dead_at:
@@ -233,7 +237,9 @@ class MatryoshkaTranscoder(nn.Module):
         aux_rows = None
         if aux_active:
             aux, aux_rows = self._run_aux(hp, d, acts, sel, W_dec, x_target, x_hat, g, need_grad, l1_term)
-            if need_grad:
+            # g now carries the aux contribution; the fused step (defer) derives d a_bj from it inside the decoder-
+            # gradient kernel when the aux branch is in its dense form, otherwise it is needed here
+            if need_grad and not (defer and (aux is None or aux.get("dense"))):
                 d_vals = hp.decode_bwd_vals(d, sel, W_dec, g, l1_term)
         scalars = hp.reduce_scalars(d, row_stats, sel, self.total_dict_size, float(cfg["l1_coeff"]),
                                     float(cfg["aux_penalty"]), aux_rows=aux_rows)
@@ -244,8 +250,10 @@ class MatryoshkaTranscoder(nn.Module):
         std = self.x_std.reshape(-1).contiguous() if hp.unit_norm else None
         if cfg.get("aux_mode", "gemm") == "gemm":
             # the reference's own dense form over the dead set, on MFMA (cheaper than k_aux row gathers per batch row)
-            return hp.aux_forward_dense(d, acts, self._cnt, float(cfg["n_batches_to_dead"]), int(cfg["top_k_aux"]),
-                                        float(cfg["aux_penalty"]), W_dec, x_target, x_hat, std, g, need_grad)
+            ctx, aux_rows = hp.aux_forward_dense(d, acts, self._cnt, float(cfg["n_batches_to_dead"]), int(cfg["top_k_aux"]),
+                                                 float(cfg["aux_penalty"]), W_dec, x_target, x_hat, std, g, need_grad)
+            self._aux_n_dead = 0 if ctx is None else ctx["n"]
+            return ctx, aux_rows
         asel, g_aux, aux_rows, d_aux = hp.aux_forward(
             d, acts, self._cnt, float(cfg["n_batches_to_dead"]), int(cfg["top_k_aux"]),
             float(cfg["aux_penalty"]), W_dec, x_target, x_hat, std, g, need_grad)
