@@ -281,28 +281,35 @@ class HotPath:
                               float(aux_penalty), _p(g), _p(g_aux), _p(aux_rows), _p(d_aux), s), "mtc_aux_fwd")
         return sel, g_aux, aux_rows, d_aux
 
+    def aux_dead_list(self, d, dead_cnt, n_batches_to_dead: float):
+        """(dead_idx int32[D], n_dead device int32[1], n_dead as a Python int).  Reads the count back: the dense aux
+        form sizes its GEMM operands with it (the reference synchronises at the same place, sae.py:331).  Callers
+        issue this right after the counters are updated and BEFORE the decode launch, so the launches that
+        follow the read-back queue up behind a long kernel instead of leaving the GPU idle."""
+        dev = dead_cnt.device
+        dead_idx = torch.empty(self.D, dtype=torch.int32, device=dev)
+        n_dead = torch.empty(1, dtype=torch.int32, device=dev)
+        check(self.lib.mtc_aux_dead_list(C.byref(d), _p(dead_cnt), float(n_batches_to_dead), _p(dead_idx), _p(n_dead),
+                                         _stream()), "mtc_aux_dead_list")
+        return dead_idx, n_dead, int(n_dead.item())
+
     def aux_forward_dense(self, d, acts, dead_cnt, n_batches_to_dead: float, top_k_aux: int, aux_penalty: float, W_dec,
-                          x_target, x_hat, std, g, need_grad: bool):
+                          x_target, x_hat, std, g, need_grad: bool, dead=None):
         """a9 in the reference's own dense form over the compacted dead set (sae.py:332-341), on MFMA: libmtc selects
         (per-row top-k_aux, ties in dead-list order) and fuses the residual / loss / gradient elementwise part; the
-        [B, n_dead] x [n_dead, A_t] product is a plain library GEMM.  Reads n_dead back once to size the operands
-        (the reference synchronises at the same place, sae.py:331).  Returns (ctx dict, aux_rows[B]); g is updated
-        in place."""
+        [B, n_dead] x [n_dead, A_t] product is a plain library GEMM.  `dead` = the result of aux_dead_list() when the
+        caller already made it.  Returns (ctx dict, aux_rows[B]); g is updated in place."""
         dev = acts.device
         lib, s = self.lib, _stream()
         B = d.B
-        dead_idx = torch.empty(self.D, dtype=torch.int32, device=dev)
-        n_dead = torch.empty(1, dtype=torch.int32, device=dev)
-        check(lib.mtc_aux_dead_list(C.byref(d), _p(dead_cnt), float(n_batches_to_dead), _p(dead_idx), _p(n_dead), s),
-              "mtc_aux_dead_list")
+        dead_idx, n_dead, n = dead if dead is not None else self.aux_dead_list(d, dead_cnt, n_batches_to_dead)
+        if n == 0:
+            return None, None            # no dead feature after all (sae.py:331: the branch returns a zero)
         row_cnt = torch.empty(B, dtype=torch.int32, device=dev)
         row_tau = torch.empty(B, dtype=torch.int32, device=dev)
         row_quota = torch.empty(B, dtype=torch.int32, device=dev)
         check(lib.mtc_aux_select(C.byref(d), _p(acts), _p(dead_idx), _p(n_dead), int(top_k_aux), _p(row_cnt), _p(row_tau),
                                  _p(row_quota), s), "mtc_aux_select")
-        n = int(n_dead.item())
-        if n == 0:
-            return None, None            # no dead feature after all (sae.py:331: the branch returns a zero)
         n_pad = (n + 7) // 8 * 8
         idx = dead_idx[:n].long()
         acts_aux = torch.empty(B, n_pad, dtype=self.dtype, device=dev)

@@ -200,6 +200,9 @@ class ShardedMatryoshkaTranscoder(MatryoshkaTranscoder):
         return sel
 
     # ------------------------------------------------------------------ step 3: decode + losses
+    def _aux_prepare(self, hp, d, aux_active: bool) -> bool:
+        return aux_active            # the sharded aux branch runs in its row-gather form (no dead-list read-back)
+
     def _aux_may_be_active(self) -> bool:
         """Same host-side bound as the single-GPU model, on the GLOBAL maximum of the dead counters so that
         every rank takes the same branch (and issues the same collectives) on the same step."""

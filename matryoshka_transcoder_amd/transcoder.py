@@ -187,8 +187,8 @@ class MatryoshkaTranscoder(nn.Module):
         if self._dead_check_in > 0:
             return False
         if getattr(self, "_aux_n_dead", 0) > 0:
-            # dead features existed one forward ago: skip the read-back, the dead list built next settles it
-            # (it reads its own count back, and an empty list switches the branch off again)
+            # dead features existed one forward ago: skip this read-back, the dead list built next (_aux_prepare)
+            # reads its own count back and an empty list switches the branch off again
             return True
         n_dead_at = float(self.config["n_batches_to_dead"])
         mx = float(self._cnt.max().item())
@@ -196,6 +196,16 @@ class MatryoshkaTranscoder(nn.Module):
             return True
         self._dead_check_in = max(int(math.ceil(n_dead_at - mx)) - 1, 0)
         return False
+
+    def _aux_prepare(self, hp, d, aux_active: bool) -> bool:
+        """Dense aux form: build the dead list (and read its length back) now, before the decode launch, so that the
+        host has a long kernel to queue the aux launches behind.  An empty list switches the branch off."""
+        self._aux_dead = None
+        if not aux_active or self.config.get("aux_mode", "gemm") != "gemm":
+            return aux_active
+        self._aux_dead = hp.aux_dead_list(d, self._cnt, float(self.config["n_batches_to_dead"]))
+        self._aux_n_dead = self._aux_dead[2]
+        return self._aux_n_dead > 0
 
     def _run_forward(self, x_source, x_target, W_enc, b_enc, W_dec, b_dec, need_grad: bool):
         self._check_inputs(x_source, x_target)
@@ -217,7 +227,7 @@ class MatryoshkaTranscoder(nn.Module):
             self._cnt = self._cnt.to(device=x_source.device, dtype=torch.float32)
         hp.build_csc(d, sel, self._cnt)                              # counters BEFORE aux (sae.py:233,242)
         self._dead_check_in -= 1
-        aux_active = self._aux_may_be_active()
+        aux_active = self._aux_prepare(hp, d, self._aux_may_be_active())
         x_hat, g, d_vals, row_stats, scalars, aux = self._decode_and_losses(
             hp, d, sel, acts, W_dec.contiguous(), b_dec.contiguous(), x_target, mean, std, need_grad, aux_active)
         from .engine import ForwardResult
@@ -250,10 +260,9 @@ class MatryoshkaTranscoder(nn.Module):
         std = self.x_std.reshape(-1).contiguous() if hp.unit_norm else None
         if cfg.get("aux_mode", "gemm") == "gemm":
             # the reference's own dense form over the dead set, on MFMA (cheaper than k_aux row gathers per batch row)
-            ctx, aux_rows = hp.aux_forward_dense(d, acts, self._cnt, float(cfg["n_batches_to_dead"]), int(cfg["top_k_aux"]),
-                                                 float(cfg["aux_penalty"]), W_dec, x_target, x_hat, std, g, need_grad)
-            self._aux_n_dead = 0 if ctx is None else ctx["n"]
-            return ctx, aux_rows
+            return hp.aux_forward_dense(d, acts, self._cnt, float(cfg["n_batches_to_dead"]), int(cfg["top_k_aux"]),
+                                        float(cfg["aux_penalty"]), W_dec, x_target, x_hat, std, g, need_grad,
+                                        dead=getattr(self, "_aux_dead", None))
         asel, g_aux, aux_rows, d_aux = hp.aux_forward(
             d, acts, self._cnt, float(cfg["n_batches_to_dead"]), int(cfg["top_k_aux"]),
             float(cfg["aux_penalty"]), W_dec, x_target, x_hat, std, g, need_grad)
