@@ -28,6 +28,29 @@ def test_library_exports_every_declared_symbol():
     assert _lib.load().mtc_version() == 1
 
 
+def test_header_is_plain_c_and_links(tmp_path):
+    """The boundary is a C ABI: include/mtc.h must compile as C99 (no C++ / HIP / torch types) and a C program must
+    link against libmtc.so and call into it."""
+    import shutil
+    import subprocess
+    from matryoshka_transcoder_amd import _lib
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "host.c"
+    src.write_text('#include <stdio.h>\n#include "mtc.h"\n'
+                   'int main(void) {\n'
+                   '    mtc_desc d = {0};\n'
+                   '    int rc = mtc_row_normalize(&d, 0, 0, 0, 0, 0);   /* rejected on the host: B = 0 */\n'
+                   '    printf("%d %d %s\\n", mtc_version(), rc, mtc_last_error());\n'
+                   '    return 0;\n}\n')
+    libdir = os.path.dirname(_lib.lib_path())
+    exe = tmp_path / "host"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    str(src), "-L", libdir, "-l:libmtc.so", f"-Wl,-rpath,{libdir}", "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split(" ", 2)
+    assert out[0] == "1" and int(out[1]) != 0 and "must be positive" in out[2]
+
+
 def test_host_side_validation_without_gpu():
     """Descriptor checks run on the host before any launch: errors, not crashes."""
     from matryoshka_transcoder_amd import _lib
