@@ -317,7 +317,7 @@ extern "C" int mtc_aux_dense_fill(const mtc_desc* d, const void* acts, const int
                                   void* acts_aux, void* stream) {
     if (check_desc(d, "mtc_aux_dense_fill")) return -1;
     MTC_REQUIRE(acts && dead_idx && n_dead_dev && row_tau_bits && row_tie_quota && acts_aux, "mtc_aux_dense_fill: null pointer");
-    MTC_REQUIRE(n_pad > 0 && n_pad <= d->D + 8, "mtc_aux_dense_fill: n_pad must be in 1..D+8");
+    MTC_REQUIRE(n_pad > 0 && n_pad <= d->D, "mtc_aux_dense_fill: n_pad must be in 1..D");
     const dim3 grid((d->B + 3) / 4), block(256);
     if (d->dtype == MTC_BF16)
         hipLaunchKernelGGL(aux_dense_fill_kernel<MTC_BF16>, grid, block, 0, as_stream(stream), acts, d->B, d->D, n_pad, dead_idx,

@@ -310,13 +310,16 @@ class HotPath:
         row_quota = torch.empty(B, dtype=torch.int32, device=dev)
         check(lib.mtc_aux_select(C.byref(d), _p(acts), _p(dead_idx), _p(n_dead), int(top_k_aux), _p(row_cnt), _p(row_tau),
                                  _p(row_quota), s), "mtc_aux_select")
-        n_pad = (n + 7) // 8 * 8
+        # operand sizes come in buckets: n_dead changes almost every step, and every new GEMM shape / allocation size
+        # costs milliseconds once (hipBLASLt solution lookup, allocator growth); the padding columns are zeros
+        step = 128 if n <= 2048 else 512 if n <= 8192 else 2048
+        n_pad = min((n + step - 1) // step * step, self.D)
         idx = dead_idx[:n].long()
         acts_aux = torch.empty(B, n_pad, dtype=self.dtype, device=dev)
         check(lib.mtc_aux_dense_fill(C.byref(d), _p(acts), _p(dead_idx), _p(n_dead), _p(row_tau), _p(row_quota), n_pad,
                                      _p(acts_aux), s), "mtc_aux_dense_fill")
-        W_dead = torch.zeros(n_pad, self.A_t, dtype=self.dtype, device=dev)
-        W_dead[:n] = W_dec.index_select(0, idx)
+        # rows >= n of W_dead only ever meet zero activations / masked gradients: any valid row will do
+        W_dead = W_dec.index_select(0, dead_idx[:n_pad].clamp(0, self.D - 1).long())
         x_hat_aux = torch.matmul(acts_aux, W_dead)                     # hipBLASLt, fp32 accumulate, one rounding
         g_aux = torch.empty(B, self.A_t, dtype=self.dtype, device=dev)
         aux_rows = torch.empty(B, dtype=torch.float32, device=dev)
