@@ -123,6 +123,8 @@ class _Comm:
 
 
 class ShardedMatryoshkaTranscoder(MatryoshkaTranscoder):
+    _overlap_ok = False        # one stream: the step is a chain of kernels and collectives
+
     def __init__(self, cfg: dict, group=None):
         if not dist.is_initialized():
             raise _lib.MtcError("ShardedMatryoshkaTranscoder needs an initialised torch.distributed process group")

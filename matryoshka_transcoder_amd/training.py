@@ -78,6 +78,8 @@ class FusedAdam(torch.optim.Optimizer):
         if not tc.training:
             raise _lib.MtcError("train_step() needs the transcoder in training mode")
         tc._defer_dvals = True          # d a_bj comes out of the decoder-gradient kernel below
+        if getattr(tc, "_side_stream", None) is None and getattr(tc, "_overlap_ok", True) and x_source.is_cuda:
+            tc._side_stream = torch.cuda.Stream(device=x_source.device)
         try:
             res = tc._run_forward(x_source, x_target, tc.W_enc, tc.b_enc, tc.W_dec, tc.b_dec, True)
         finally:
@@ -93,6 +95,7 @@ class FusedAdam(torch.optim.Optimizer):
             row_map[a["idx"]] = torch.arange(a["n"], dtype=torch.int32, device=res.g.device)
             extra = (row_map,) + tuple(t.contiguous() for t in hp.aux_extra_rows(a, res.x_norm))
         elif res.aux is not None:
+            tc._join_csc()
             dW_dec, dW_encT, db_enc, db_dec = tc._run_backward(res, None)
             tc.W_dec.grad, tc.W_enc.grad, tc.b_enc.grad, tc.b_dec.grad = dW_dec, dW_encT.t(), db_enc, db_dec
             self.step(project=True)
@@ -111,12 +114,31 @@ class FusedAdam(torch.optim.Optimizer):
         if not m_e.is_contiguous():
             se["exp_avg"], se["exp_avg_sq"] = m_e.contiguous().t(), v_e.contiguous().t()
             m_e, v_e = se["exp_avg"].t(), se["exp_avg_sq"].t()
+        def update_b_dec():
+            db_dec = hp.colsum(res.desc, res.g)
+            hp.adam_flat(tc.b_dec.data, db_dec, sbd["exp_avg"], sbd["exp_avg_sq"], hy["b_dec"])
+
+        overlapped = tc._csc_event is not None          # this step runs two streams (see _run_forward)
+        e_b = None
+        if overlapped:
+            # the b_dec update only needs g: it runs on the side stream underneath the two gradient kernels
+            main, side = torch.cuda.current_stream(), tc._side_stream
+            e_g = torch.cuda.Event()
+            e_g.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(e_g)
+                update_b_dec()
+                e_b = torch.cuda.Event()
+                e_b.record(side)
+        tc._join_csc()
         hp.fused_backward_adam(res.desc, res.sel, res.g, res.d_vals, res.x_norm, None, tc.W_dec.data,
                                (sd["exp_avg"], sd["exp_avg_sq"]), W_encT.data, (m_e, v_e), tc.b_enc.data,
                                (sb["exp_avg"], sb["exp_avg_sq"]), hy["W_dec"], hy["W_enc"], hy["b_enc"],
                                l1_term=float(tc.config["l1_coeff"]) / (res.desc.B * tc.total_dict_size), extra=extra)
-        db_dec = hp.colsum(res.desc, res.g)
-        hp.adam_flat(tc.b_dec.data, db_dec, sbd["exp_avg"], sbd["exp_avg_sq"], hy["b_dec"])
+        if e_b is not None:
+            torch.cuda.current_stream().wait_event(e_b)     # every later reader of b_dec / g is ordered behind the side stream
+        else:
+            update_b_dec()
         return out
 
     @torch.no_grad()

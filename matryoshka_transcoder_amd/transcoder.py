@@ -197,6 +197,15 @@ class MatryoshkaTranscoder(nn.Module):
         self._dead_check_in = max(int(math.ceil(n_dead_at - mx)) - 1, 0)
         return False
 
+    _OVERLAP_MIN_ELEMS = 1 << 25       # below this a step is launch-bound and a second stream only adds host work
+
+    def _join_csc(self):
+        """Make the current stream wait for a CSC build that was issued on the side stream."""
+        ev = getattr(self, "_csc_event", None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+            self._csc_event = None
+
     def _aux_prepare(self, hp, d, aux_active: bool) -> bool:
         """Dense aux form: build the dead list (and read its length back) now, before the decode launch, so that the
         host has a long kernel to queue the aux launches behind.  An empty list switches the branch off."""
@@ -225,8 +234,24 @@ class MatryoshkaTranscoder(nn.Module):
         sel = self._select(hp, d, acts, self.training)
         if self._cnt.device != x_source.device or self._cnt.dtype != torch.float32:
             self._cnt = self._cnt.to(device=x_source.device, dtype=torch.float32)
-        hp.build_csc(d, sel, self._cnt)                              # counters BEFORE aux (sae.py:233,242)
+        # counters BEFORE aux (sae.py:233,242).  In the fused training step the CSC build (a chain of small latency-bound
+        # kernels nobody needs before the gradient kernels) runs on a side stream underneath the decode launch.
+        side = getattr(self, "_side_stream", None)
+        self._csc_event = None
+        if side is not None and getattr(self, "_defer_dvals", False) and B * hp.D >= self._OVERLAP_MIN_ELEMS:
+            main = torch.cuda.current_stream()
+            e_sel = torch.cuda.Event()
+            e_sel.record(main)
+            with torch.cuda.stream(side):                            # workspace / outputs come from the side stream's pool
+                side.wait_event(e_sel)
+                hp.build_csc(d, sel, self._cnt)
+                self._csc_event = torch.cuda.Event()
+                self._csc_event.record(side)
+        else:
+            hp.build_csc(d, sel, self._cnt)
         self._dead_check_in -= 1
+        if self._dead_check_in <= 0:
+            self._join_csc()                                         # the dead-feature check below reads the counters
         aux_active = self._aux_prepare(hp, d, self._aux_may_be_active())
         x_hat, g, d_vals, row_stats, scalars, aux = self._decode_and_losses(
             hp, d, sel, acts, W_dec.contiguous(), b_dec.contiguous(), x_target, mean, std, need_grad, aux_active)

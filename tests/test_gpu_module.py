@@ -223,3 +223,30 @@ def test_fused_train_step_equals_autograd_path(name, gpu_lib):
             assert torch.equal(oa.state[pa]["exp_avg_sq"], ob.state[pb]["exp_avg_sq"]), n
         assert torch.equal(ma.threshold, mb.threshold)
         assert torch.equal(ma.num_batches_not_active, mb.num_batches_not_active)
+
+
+@pytest.mark.parametrize("name", ["fp32_plain", "bf16_unit", "bf16_aux"])
+def test_two_stream_step_is_bit_identical(name, gpu_lib):
+    """FusedAdam.train_step issues the CSC build and the b_dec update on a side stream at large sizes; forced on here
+    at fixture size, it must give the same bits as the single-stream step (ordering is by events only)."""
+    from matryoshka_transcoder_amd.training import FusedAdam
+    fx, cfg = load_golden(name)
+    ma, _ = _model(fx, cfg)
+    mb, _ = _model(fx, cfg)
+    ma._OVERLAP_MIN_ELEMS = 0
+    mb._overlap_ok = False
+    for m in (ma, mb):
+        m.num_batches_not_active = fx["cnt0"].clone().to(DEV)
+    oa = FusedAdam(ma, lr=cfg["lr"], betas=(cfg["beta1"], cfg["beta2"]))
+    ob = FusedAdam(mb, lr=cfg["lr"], betas=(cfg["beta1"], cfg["beta2"]))
+    for rep in range(4):
+        for s in fx["steps"]:
+            xs, xt = s["x_source"].to(DEV), s["x_target"].to(DEV)
+            out_a, out_b = oa.train_step(xs, xt), ob.train_step(xs, xt)
+            for k in out_a:
+                assert torch.equal(out_a[k], out_b[k]), k
+    assert ma._side_stream is not None and getattr(mb, "_side_stream", None) is None
+    for (n, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+        assert torch.equal(pa, pb), n
+        assert torch.equal(oa.state[pa]["exp_avg_sq"], ob.state[pb]["exp_avg_sq"]), n
+    assert torch.equal(ma.num_batches_not_active, mb.num_batches_not_active)
