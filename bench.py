@@ -90,9 +90,14 @@ def cpu_baseline(workload, dtype, budget_rows=512, steps=64):
 
 
 def stage_times(tc, opt, pool, reps=5):
-    """Per-stage device time of one step, HIP events on the launch stream (torch's current stream)."""
+    """Per-stage device time of one step, HIP events on the launch stream (torch's current stream).  Stages are timed
+    one after the other on ONE stream: the side-stream overlap of the production step (CSC build under the decode,
+    b_dec update under the gradient kernels) is switched off here, so the stage times add up to slightly more than
+    the measured step."""
     from matryoshka_transcoder_amd import engine
     hp = tc.hot_path()
+    overlap_was, side_was = getattr(tc, "_overlap_ok", True), getattr(tc, "_side_stream", None)
+    tc._overlap_ok, tc._side_stream = False, None
     names, evs = [], []
     orig = {}
 
@@ -122,6 +127,7 @@ def stage_times(tc, opt, pool, reps=5):
             acc.setdefault(n, []).append(e0.elapsed_time(e1))
     for n, fn in orig.items():
         setattr(hp, n, fn)
+    tc._overlap_ok, tc._side_stream = overlap_was, side_was
     out = {}
     # several calls of one stage inside a step (adam_flat x3) are summed per step
     for n, v in acc.items():
