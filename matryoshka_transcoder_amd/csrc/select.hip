@@ -445,14 +445,45 @@ __device__ __forceinline__ uint32_t mbcnt64(uint64_t m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
+// cheap superset test: does this 8-element chunk hold ANY bit pattern >= the bound?  (NaNs and negatives, which cannot
+// come out of the encoder's ReLU anyway, also say yes; the exact test below rejects them.)
+typedef __attribute__((ext_vector_type(2))) unsigned short us2;
+template <int DT> __device__ __forceinline__ bool chunk_may_hold(const Raw<DT>& r, uint32_t guess);
+template <> __device__ __forceinline__ bool chunk_may_hold<MTC_BF16>(const Raw<MTC_BF16>& r, uint32_t guess) {
+    const uint32_t x0 = r.v[0], x1 = r.v[1], x2 = r.v[2], x3 = r.v[3];
+    const us2 a = __builtin_elementwise_max(__builtin_bit_cast(us2, x0), __builtin_bit_cast(us2, x1));
+    const us2 b = __builtin_elementwise_max(__builtin_bit_cast(us2, x2), __builtin_bit_cast(us2, x3));
+    const us2 c = __builtin_elementwise_max(a, b);
+    const uint32_t mx = max((uint32_t)c.x, (uint32_t)c.y);
+    return mx >= (guess >> 16);
+}
+template <> __device__ __forceinline__ bool chunk_may_hold<MTC_F32>(const Raw<MTC_F32>& r, uint32_t guess) {
+    uint32_t mx = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float fa = r.a[i], fb = r.b[i];
+        mx = max(mx, max(__float_as_uint(fa), __float_as_uint(fb)));
+    }
+    return mx >= guess;
+}
+
+// Wave per row.  The row streams through registers (U chunks of 8 elements per lane in flight, the next block
+// requested before this one is looked at); a chunk that MAY hold a candidate (one packed-max test, ~0.5 % of the
+// elements are candidates) is appended, in column order, to a per-wave queue in LDS.  Whenever the queue holds more
+// than a wave's worth, 64 queued chunks are examined exactly, one per lane, and their candidates are written out in
+// order.  The exact test / ordered compaction therefore runs once per ~25 loads instead of once per load.
+constexpr int CAND_QCAP = 128;
 template <int DT>
 __global__ __launch_bounds__(256) void select_candidates_kernel(const void* __restrict__ acts, int B, int D, int C,
                                                                 const uint32_t* __restrict__ carry, void* __restrict__ cand_vals,
                                                                 int32_t* __restrict__ cand_cols, uint32_t* __restrict__ cand_cnt) {
     typedef typename DType<DT>::T T;
     constexpr int U = DT == MTC_BF16 ? 8 : 4;
+    __shared__ Raw<DT> q_raw[4][CAND_QCAP];
+    __shared__ int q_chunk[4][CAND_QCAP];
     const int lane = threadIdx.x & 63;
-    const int row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int w = threadIdx.x >> 6;
+    const int row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + w);
     if (row >= B) return;
     const uint32_t guess = carry[0];
     if (guess == 0) return;
@@ -461,6 +492,52 @@ __global__ __launch_bounds__(256) void select_candidates_kernel(const void* __re
     int32_t* cout = cand_cols + (size_t)row * C;
     const int nch = D >> 3;
     uint32_t out = 0;
+    int qn = 0;                                          // queued chunks (wave-uniform)
+
+    // exact pass over queued chunks [0, qn): one chunk per lane, candidates leave in (chunk, element) order
+    auto drain = [&]() {
+        for (int q0 = 0; q0 < qn; q0 += 64) {
+            const int e = q0 + lane;
+            float v[8];
+            uint32_t m = 0;
+            int c = 0;
+            if (e < qn) {
+                const Raw<DT> r = q_raw[w][e];
+                c = q_chunk[w][e];
+                unpack(r, v);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const uint32_t k = __float_as_uint(v[i]);
+                    if (k >= guess && k <= 0x7f800000u) m |= 1u << i;
+                }
+            }
+            if (__ballot(m != 0) == 0) continue;         // wave-uniform
+            // exclusive prefix of popc(m) over the lanes from ballots of its bit planes
+            const uint32_t ns = __popc(m);
+            const uint64_t b0 = __ballot((ns & 1u) != 0), b1 = __ballot((ns & 2u) != 0);
+            const uint64_t b2 = __ballot((ns & 4u) != 0), b3 = __ballot((ns & 8u) != 0);
+            uint32_t pos = out + mbcnt64(b0);
+            uint32_t tot = (uint32_t)__popcll(b0);
+            if (b1) { pos += 2u * mbcnt64(b1); tot += 2u * (uint32_t)__popcll(b1); }
+            if (b2) { pos += 4u * mbcnt64(b2); tot += 4u * (uint32_t)__popcll(b2); }
+            if (b3) { pos += 8u * mbcnt64(b3); tot += 8u * (uint32_t)__popcll(b3); }
+            uint32_t mm = m;
+            while (__ballot(mm != 0)) {
+                if (mm) {
+                    const int i = __ffs(mm) - 1;
+                    float val = v[0];
+#pragma unroll
+                    for (int q = 1; q < 8; ++q) val = i == q ? v[q] : val;
+                    if (pos < (uint32_t)C) { DType<DT>::st(vout + pos, val); cout[pos] = c * 8 + i; }
+                    ++pos;
+                    mm &= mm - 1;
+                }
+            }
+            out += tot;
+        }
+        qn = 0;
+    };
+
     Raw<DT> nxt[U];
 #pragma unroll
     for (int u = 0; u < U; ++u)
@@ -477,43 +554,19 @@ __global__ __launch_bounds__(256) void select_candidates_kernel(const void* __re
         for (int u = 0; u < U; ++u) {
             if (cb + 64 * u >= nch) break;                   // wave-uniform
             const int c = cb + 64 * u + lane;
-            float v[8];
-            uint32_t m = 0;
-            if (c < nch) {
-                unpack(cur[u], v);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const uint32_t k = __float_as_uint(v[i]);
-                    if (k >= guess && k <= 0x7f800000u) m |= 1u << i;
-                }
+            const bool may = c < nch && chunk_may_hold<DT>(cur[u], guess);
+            const uint64_t bal = __ballot(may);
+            if (bal == 0) continue;                          // wave-uniform
+            if (may) {
+                const int e = qn + (int)mbcnt64(bal);
+                q_raw[w][e] = cur[u];
+                q_chunk[w][e] = c;
             }
-            if (__ballot(m != 0) == 0) continue;             // wave-uniform
-            // exclusive prefix of popc(m) over the lanes from ballots of its bit planes (most lanes hold 0 or 1)
-            const uint32_t ns = __popc(m);
-            const uint64_t b0 = __ballot((ns & 1u) != 0), b1 = __ballot((ns & 2u) != 0);
-            const uint64_t b2 = __ballot((ns & 4u) != 0), b3 = __ballot((ns & 8u) != 0);
-            uint32_t pos = out + mbcnt64(b0);
-            uint32_t tot = (uint32_t)__popcll(b0);
-            if (b1) { pos += 2u * mbcnt64(b1); tot += 2u * (uint32_t)__popcll(b1); }
-            if (b2) { pos += 4u * mbcnt64(b2); tot += 4u * (uint32_t)__popcll(b2); }
-            if (b3) { pos += 8u * mbcnt64(b3); tot += 8u * (uint32_t)__popcll(b3); }
-            // one candidate per lane per round (a lane rarely holds two): 8 predicated store blocks, one per
-            // element position, cost ~10x more instructions than this loop
-            uint32_t mm = m;
-            while (__ballot(mm != 0)) {
-                if (mm) {
-                    const int i = __ffs(mm) - 1;
-                    float val = v[0];
-#pragma unroll
-                    for (int q = 1; q < 8; ++q) val = i == q ? v[q] : val;
-                    if (pos < (uint32_t)C) { DType<DT>::st(vout + pos, val); cout[pos] = c * 8 + i; }
-                    ++pos;
-                    mm &= mm - 1;
-                }
-            }
-            out += tot;
+            qn += (int)__popcll(bal);
+            if (qn > CAND_QCAP - 64) drain();
         }
     }
+    drain();
     // zero the unused tail of the compact row (the select passes treat 0 as "not a candidate")
     const uint32_t n_kept = min(out, (uint32_t)C);
     const uint32_t al = (n_kept + 7u) & ~7u;
