@@ -158,7 +158,19 @@ def main():
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=torch.device(device))
+        # RCCL prints a version banner on stdout when its communicator comes up; the contract is ONE JSON line on
+        # stdout, so fd 1 points at stderr until the communicator exists
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=torch.device(device))
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     cfg, B = make_cfg(args.workload, dtype, device, args.unit_norm)
     A, D, k = cfg["act_size"], cfg["prefix_sizes"][-1], cfg["top_k"]

@@ -324,6 +324,17 @@ int mtc_aux_residual(const mtc_desc* d, const void* x_hat_aux, const void* x_tar
                      float aux_penalty, void* g, void* g_aux, float* aux_rows, void* stream);
 int mtc_aux_mask(int32_t dtype, uint64_t n, const void* acts_aux, void* d_acts_aux, void* stream);
 
+/* a9 over a feature-sharded dictionary ("per-row top-k_aux merge").  Each rank runs mtc_aux_select on its
+ * local dead columns, mtc_aux_row_candidates packs the values of that local top-k_aux into cand[B][k_pad] (zero padded)
+ * for an all-gather; mtc_aux_select on the gathered [B][world*k_pad] matrix gives the global per-row threshold and tie
+ * quota; mtc_aux_count_at counts the local entries above / at that threshold (the at-threshold counts are all-gathered
+ * and the quota is granted in (rank, feature) order); mtc_aux_dense_fill then writes the local part of acts_aux. */
+int mtc_aux_row_candidates(const mtc_desc* d, const void* acts, const int32_t* dead_idx, const int32_t* n_dead_dev,
+                           const uint32_t* row_tau_bits, const uint32_t* row_tie_quota, int32_t k_pad, void* cand,
+                           void* stream);
+int mtc_aux_count_at(const mtc_desc* d, const void* acts, const int32_t* dead_idx, const int32_t* n_dead_dev,
+                     const uint32_t* row_tau_bits, int32_t* row_gt, int32_t* row_eq, void* stream);
+
 /* a15 helpers: CSR <-> dense [B][D] in the model dtype (encode returns dense, decode takes it) */
 int mtc_densify(const mtc_desc* d, const int32_t* row_ptr, const int32_t* col_idx, const void* vals,
                 int32_t max_col, void* dense, void* stream);

@@ -244,6 +244,72 @@ __global__ __launch_bounds__(256) void aux_dense_fill_kernel(const void* __restr
     }
 }
 
+// Feature-sharded aux selection, step 1: the values of a row's local top-k_aux dead activations (threshold / tie quota
+// from aux_select on the LOCAL dead columns), left-packed into cand[row][0..k_pad) and zero-padded -- what each rank
+// contributes to the all-gather from which the global per-row threshold is found.  Wave per row.
+template <int DT>
+__global__ __launch_bounds__(256) void aux_row_candidates_kernel(const void* __restrict__ acts, int B, int D, int k_pad,
+                                                                 const int32_t* __restrict__ dead_idx,
+                                                                 const int32_t* __restrict__ n_dead_p,
+                                                                 const uint32_t* __restrict__ row_tau,
+                                                                 const uint32_t* __restrict__ row_quota, void* __restrict__ cand) {
+    typedef typename DType<DT>::T T;
+    const int lane = threadIdx.x & 63;
+    const int row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (row >= B) return;
+    const int n_dead = *n_dead_p;
+    const uint32_t tau = row_tau[row], quota = row_quota[row];
+    const size_t base = (size_t)row * D;
+    T* o = reinterpret_cast<T*>(cand) + (size_t)row * k_pad;
+    uint32_t out = 0, ties_seen = 0;
+    for (int i0 = 0; i0 < n_dead; i0 += 64) {
+        const int i = i0 + lane;
+        uint32_t k = 0; T raw = 0;
+        if (i < n_dead) { const int col = dead_idx[i]; raw = reinterpret_cast<const T*>(acts)[base + col]; k = key_of<DT>(acts, base + col); }
+        const bool ok = k != 0 && k <= 0x7f800000u;
+        const bool eq = ok && quota && k == tau;
+        bool sel = ok && k > tau;
+        const uint64_t eqb = __ballot(eq);
+        if (eqb) {
+            const uint32_t rank = ties_seen + (uint32_t)__popcll(eqb & ((1ull << lane) - 1ull));
+            if (eq && rank < quota) sel = true;
+            ties_seen += (uint32_t)__popcll(eqb);
+        }
+        const uint64_t sb = __ballot(sel);
+        if (sel) {
+            const uint32_t pos = out + (uint32_t)__popcll(sb & ((1ull << lane) - 1ull));
+            if (pos < (uint32_t)k_pad) o[pos] = raw;
+        }
+        out += (uint32_t)__popcll(sb);
+    }
+    for (uint32_t i = min(out, (uint32_t)k_pad) + lane; i < (uint32_t)k_pad; i += 64) o[i] = (T)0;
+}
+
+// step 2: per row, how many local dead activations lie above / exactly at the GLOBAL threshold (bits; 0 = take every
+// positive one).  Wave per row.
+template <int DT>
+__global__ __launch_bounds__(256) void aux_count_at_kernel(const void* __restrict__ acts, int B, int D,
+                                                           const int32_t* __restrict__ dead_idx,
+                                                           const int32_t* __restrict__ n_dead_p,
+                                                           const uint32_t* __restrict__ row_tau, int32_t* __restrict__ row_gt,
+                                                           int32_t* __restrict__ row_eq) {
+    const int lane = threadIdx.x & 63;
+    const int row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (row >= B) return;
+    const int n_dead = *n_dead_p;
+    const uint32_t tau = row_tau[row];
+    const size_t base = (size_t)row * D;
+    uint32_t gt = 0, eq = 0;
+    for (int i = lane; i < n_dead; i += 64) {
+        const uint32_t k = key_of<DT>(acts, base + dead_idx[i]);
+        const bool ok = k != 0 && k <= 0x7f800000u;
+        gt += (ok && k > tau) ? 1u : 0u;
+        eq += (ok && tau != 0 && k == tau) ? 1u : 0u;
+    }
+    gt = wave_sum_u32(gt); eq = wave_sum_u32(eq);
+    if (lane == 0) { row_gt[row] = (int32_t)gt; row_eq[row] = (int32_t)eq; }
+}
+
 // d[i] = 0 where the aux activation is not selected (ReLU / TopK mask of the aux branch's backward)
 template <int DT>
 __global__ __launch_bounds__(256) void aux_mask_kernel(size_t n, const void* __restrict__ acts_aux, void* __restrict__ dvals) {
@@ -326,6 +392,36 @@ extern "C" int mtc_aux_dense_fill(const mtc_desc* d, const void* acts, const int
         hipLaunchKernelGGL(aux_dense_fill_kernel<MTC_F32>, grid, block, 0, as_stream(stream), acts, d->B, d->D, n_pad, dead_idx,
                            n_dead_dev, row_tau_bits, row_tie_quota, acts_aux);
     return check_launch("mtc_aux_dense_fill");
+}
+
+extern "C" int mtc_aux_row_candidates(const mtc_desc* d, const void* acts, const int32_t* dead_idx, const int32_t* n_dead_dev,
+                                      const uint32_t* row_tau_bits, const uint32_t* row_tie_quota, int32_t k_pad, void* cand,
+                                      void* stream) {
+    if (check_desc(d, "mtc_aux_row_candidates")) return -1;
+    MTC_REQUIRE(acts && dead_idx && n_dead_dev && row_tau_bits && row_tie_quota && cand, "mtc_aux_row_candidates: null pointer");
+    MTC_REQUIRE(k_pad > 0, "mtc_aux_row_candidates: k_pad must be positive");
+    const dim3 grid((d->B + 3) / 4), block(256);
+    if (d->dtype == MTC_BF16)
+        hipLaunchKernelGGL(aux_row_candidates_kernel<MTC_BF16>, grid, block, 0, as_stream(stream), acts, d->B, d->D, k_pad, dead_idx,
+                           n_dead_dev, row_tau_bits, row_tie_quota, cand);
+    else
+        hipLaunchKernelGGL(aux_row_candidates_kernel<MTC_F32>, grid, block, 0, as_stream(stream), acts, d->B, d->D, k_pad, dead_idx,
+                           n_dead_dev, row_tau_bits, row_tie_quota, cand);
+    return check_launch("mtc_aux_row_candidates");
+}
+
+extern "C" int mtc_aux_count_at(const mtc_desc* d, const void* acts, const int32_t* dead_idx, const int32_t* n_dead_dev,
+                                const uint32_t* row_tau_bits, int32_t* row_gt, int32_t* row_eq, void* stream) {
+    if (check_desc(d, "mtc_aux_count_at")) return -1;
+    MTC_REQUIRE(acts && dead_idx && n_dead_dev && row_tau_bits && row_gt && row_eq, "mtc_aux_count_at: null pointer");
+    const dim3 grid((d->B + 3) / 4), block(256);
+    if (d->dtype == MTC_BF16)
+        hipLaunchKernelGGL(aux_count_at_kernel<MTC_BF16>, grid, block, 0, as_stream(stream), acts, d->B, d->D, dead_idx, n_dead_dev,
+                           row_tau_bits, row_gt, row_eq);
+    else
+        hipLaunchKernelGGL(aux_count_at_kernel<MTC_F32>, grid, block, 0, as_stream(stream), acts, d->B, d->D, dead_idx, n_dead_dev,
+                           row_tau_bits, row_gt, row_eq);
+    return check_launch("mtc_aux_count_at");
 }
 
 extern "C" int mtc_aux_residual(const mtc_desc* d, const void* x_hat_aux, const void* x_target, const void* x_hat,

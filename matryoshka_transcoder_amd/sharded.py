@@ -80,6 +80,16 @@ def tie_before(all_eq: torch.Tensor, rank: int) -> torch.Tensor:
     return (earlier_rows + earlier_ranks).to(torch.int32)
 
 
+def _mm_f32(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """a @ b with an fp32 result (partial sums that are all-reduced must not be rounded to bf16 first)."""
+    if a.dtype == torch.float32:
+        return torch.mm(a, b)
+    try:
+        return torch.mm(a, b, out_dtype=torch.float32)
+    except (TypeError, RuntimeError, NotImplementedError):
+        return torch.mm(a.float(), b.float())
+
+
 class _Comm:
     """torch.distributed on device tensors.  backend "nccl" is RCCL on ROCm; with "gloo" (tests)
     device tensors are staged through the host."""
@@ -221,7 +231,64 @@ class ShardedMatryoshkaTranscoder(MatryoshkaTranscoder):
         return False
 
     def _run_aux(self, hp, d, acts, sel, W_dec, x_target, x_hat, g, need_grad, l1_term):
-        """Auxiliary dead-feature loss (sae.py:318-347) over a feature-sharded dictionary.  The per-row
+        """Auxiliary dead-feature loss (sae.py:318-347) over a feature-sharded dictionary, dense form (default): every
+        rank holds its dead features' columns of acts_aux and rows of W_dec, so the aux reconstruction is a local GEMM
+        + one fp32 all-reduce, and the three backward products are local GEMMs whose rows ride into the fused gradient
+        kernels.  The per-row top-k_aux over ALL dead features: local top-k_aux values per row (mtc_aux_select +
+        mtc_aux_row_candidates) -> all-gather -> mtc_aux_select on the gathered [B, world*k] matrix = global threshold
+        and tie quota per row -> local counts at the threshold (mtc_aux_count_at), all-gathered so that ties are granted
+        in (rank, feature) order -> mtc_aux_dense_fill.  Three small collectives + the all-reduce."""
+        cfg, comm = self.config, self.comm
+        if cfg.get("aux_mode", "gemm") != "gemm":
+            return self._run_aux_sparse(hp, d, acts, sel, W_dec, x_target, x_hat, g, need_grad, l1_term)
+        lib, s, dev = hp.lib, _stream(), acts.device
+        B, A_t, Dl, W = d.B, hp.A_t, hp.D, comm.world
+        k_aux = int(cfg["top_k_aux"])
+        k_pad = (k_aux + 7) // 8 * 8
+        dead_idx, n_dead, n = hp.aux_dead_list(d, self._cnt, float(cfg["n_batches_to_dead"]))
+        i32 = dict(dtype=torch.int32, device=dev)
+        row_cnt, row_tau, row_quota = (torch.empty(B, **i32) for _ in range(3))
+        check(lib.mtc_aux_select(C.byref(d), _p(acts), _p(dead_idx), _p(n_dead), k_aux, _p(row_cnt), _p(row_tau), _p(row_quota), s),
+              "mtc_aux_select")
+        cand = torch.empty(B, k_pad, dtype=self.dtype, device=dev)
+        check(lib.mtc_aux_row_candidates(C.byref(d), _p(acts), _p(dead_idx), _p(n_dead), _p(row_tau), _p(row_quota), k_pad,
+                                         _p(cand), s), "mtc_aux_row_candidates")
+        allc = comm.all_gather(cand).permute(1, 0, 2).reshape(B, W * k_pad).contiguous()
+        d2 = _lib.make_desc(B, hp.A_s, hp.A_t, W * k_pad, [W * k_pad], hp.code, False)
+        idx2 = torch.arange(W * k_pad, **i32)
+        n2 = torch.full((1,), W * k_pad, **i32)
+        g_cnt, g_tau, g_quota = (torch.empty(B, **i32) for _ in range(3))
+        check(lib.mtc_aux_select(C.byref(d2), _p(allc), _p(idx2), _p(n2), k_aux, _p(g_cnt), _p(g_tau), _p(g_quota), s),
+              "mtc_aux_select")
+        gt_loc, eq_loc = torch.empty(B, **i32), torch.empty(B, **i32)
+        check(lib.mtc_aux_count_at(C.byref(d), _p(acts), _p(dead_idx), _p(n_dead), _p(g_tau), _p(gt_loc), _p(eq_loc), s),
+              "mtc_aux_count_at")
+        all_eq = comm.all_gather(eq_loc)                                         # [world, B]
+        before = all_eq[:comm.rank].sum(0, dtype=torch.int32) if comm.rank > 0 else torch.zeros(B, **i32)
+        take = torch.minimum((g_quota - before).clamp_min(0), eq_loc).contiguous()
+        # local part of acts_aux over the local dead set (bucketed width, zero padding), local GEMM, fp32 all-reduce
+        step = 128 if n <= 2048 else 512 if n <= 8192 else 2048
+        n_pad = max(min((n + step - 1) // step * step, Dl), 8)
+        acts_aux = torch.empty(B, n_pad, dtype=self.dtype, device=dev)
+        check(lib.mtc_aux_dense_fill(C.byref(d), _p(acts), _p(dead_idx), _p(n_dead), _p(g_tau), _p(take), n_pad, _p(acts_aux), s),
+              "mtc_aux_dense_fill")
+        W_dead = W_dec.index_select(0, dead_idx[:n_pad].clamp(0, Dl - 1).long())
+        part = _mm_f32(acts_aux, W_dead)
+        comm.all_reduce(part)
+        x_hat_aux = part.to(self.dtype)
+        g_aux = torch.empty(B, A_t, dtype=self.dtype, device=dev)
+        aux_rows = torch.empty(B, dtype=torch.float32, device=dev)
+        std = self.x_std.reshape(-1).contiguous() if hp.unit_norm else None
+        dr = _lib.make_desc(B, hp.A_s, hp.A_t, Dl, hp.prefix, hp.code, hp.unit_norm)
+        check(lib.mtc_aux_residual(C.byref(dr), _p(x_hat_aux), _p(x_target), _p(x_hat), _p(std), float(cfg["aux_penalty"]), _p(g),
+                                   _p(g_aux), _p(aux_rows), s), "mtc_aux_residual")
+        ctx = dict(dense=True, n=n)
+        if need_grad:
+            ctx.update(idx=dead_idx[:n].long(), acts_aux=acts_aux, W_dead=W_dead, g_aux=g_aux)
+        return ctx, aux_rows
+
+    def _run_aux_sparse(self, hp, d, acts, sel, W_dec, x_target, x_hat, g, need_grad, l1_term):
+        """Row-gather form of the same branch (`aux_mode="sparse"`; kept as the cross-check of the dense form).  The per-row
         top-k_aux over ALL dead features is found from an all-gather of every rank's local per-row
         candidates (k_aux values per row), ties at a row's threshold are granted in (rank, feature) order
         from an all-gather of the tie counts, the partial reconstructions are summed with an all-reduce
@@ -333,7 +400,8 @@ class ShardedMatryoshkaTranscoder(MatryoshkaTranscoder):
         aux, aux_rows = None, None
         if aux_active:
             aux, aux_rows = self._run_aux(hp, d, acts, sel, W_dec, x_target, x_hat, g, need_grad, l1_term)
-        defer = getattr(self, "_defer_dvals", False) and not aux_active
+        # the fused step derives d a_bj inside the decoder-gradient kernel, also with the dense aux branch active
+        defer = getattr(self, "_defer_dvals", False) and (aux is None or bool(aux.get("dense")))
         d_vals = hp.decode_bwd_vals(d, sel, W_dec, g, l1_term) if need_grad and not defer else None
         scalars = hp.reduce_scalars(d, row_stats, sel, self.total_dict_size, float(cfg["l1_coeff"]),
                                     float(cfg["aux_penalty"]), aux_rows=aux_rows, nnz_abs_override=nnz_abs)

@@ -25,7 +25,8 @@ def _cfg(dt, unit, aux=False):
     # is active from the third step on
     return dict(seed=49, prefix_sizes=[256, 768, 1792, 4096], act_size=256, top_k=32, top_k_aux=64,
                 aux_penalty=1 / 32, n_batches_to_dead=2 if aux else 20, l1_coeff=1e-3, dtype=dt, device="cuda:0",
-                input_unit_norm=unit, lr=3e-4, beta1=0.9, beta2=0.99)
+                input_unit_norm=unit, lr=3e-4, beta1=0.9, beta2=0.99,
+                aux_mode=aux if isinstance(aux, str) else "gemm")     # aux = "gemm" | "sparse": form of the aux branch
 
 
 def _batches(dt, n=3, B=192):
@@ -83,16 +84,15 @@ def _worker(rank, world, port, dt_name, unit, fused, aux, ret):
 
 @pytest.mark.parametrize("dt_name,unit,fused,aux", [("float32", False, False, False), ("bfloat16", True, False, False),
                                                     ("float32", False, True, False), ("bfloat16", True, True, False),
-                                                    ("float32", False, True, True), ("float32", True, False, True),
-                                                    ("bfloat16", True, True, True)])
+                                                    ("float32", False, True, "gemm"), ("float32", True, False, "gemm"),
+                                                    ("bfloat16", True, True, "gemm"), ("float32", True, True, "sparse"),
+                                                    ("bfloat16", True, True, "sparse")])
 def test_sharded_matches_single_gpu(dt_name, unit, fused, aux, gpu_lib):
     from matryoshka_transcoder_amd.training import FusedAdam
     from matryoshka_transcoder_amd.transcoder import MatryoshkaTranscoder
     dt = getattr(torch, dt_name)
     cfg = _cfg(dt, unit, aux)
-    # the sharded model runs the row-gather form of the aux branch: compare like with like (the dense GEMM form of
-    # the single-GPU default is checked against the oracle in test_gpu_kernels.py)
-    ref = MatryoshkaTranscoder(dict(cfg, aux_mode="sparse"))
+    ref = MatryoshkaTranscoder(cfg)          # same form of the aux branch (dense GEMMs or row gathers) on both sides
     ref_log = _train(ref, FusedAdam(ref, lr=cfg["lr"], betas=(cfg["beta1"], cfg["beta2"])), _batches(dt, n=6 if aux else 3))
     if aux:
         assert ref_log[-1]["aux_loss"] > 0, "the test configuration must make the auxiliary loss active"
