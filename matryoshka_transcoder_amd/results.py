@@ -19,61 +19,63 @@ import torch
 
 
 def _jsonable(obj: Any) -> Any:
-    if isinstance(obj, (torch.dtype, torch.device)):
-        return str(obj)
+    """dtype / device objects become their string form; containers are walked."""
     if isinstance(obj, dict):
-        return {k: _jsonable(v) for k, v in obj.items()}
-    if isinstance(obj, (list, tuple)):
-        return [_jsonable(v) for v in obj]
-    return obj
+        return {key: _jsonable(val) for key, val in obj.items()}
+    if isinstance(obj, (tuple, list)):
+        return [_jsonable(val) for val in obj]
+    return str(obj) if isinstance(obj, (torch.device, torch.dtype)) else obj
+
+
+def _dump(path: Path, payload: Any) -> None:
+    path.parent.mkdir(parents=True, exist_ok=True)
+    path.write_text(json.dumps(_jsonable(payload), indent=2), encoding="utf-8")
 
 
 class CleanResultsManager:
+    """Writes one run under `{base_dir}/{model}/layer{L}/{steps}/` (see the module docstring for the files)."""
+
     def __init__(self, base_dir: str = "results") -> None:
         self.base_dir = Path(base_dir)
         self.base_dir.mkdir(parents=True, exist_ok=True)
 
+    # -- paths ---------------------------------------------------------------------------------------------
     def create_experiment_dir(self, model_name: str, layer: int, steps: int, description: str = "") -> Path:
-        run_dir = self.base_dir / model_name / f"layer{layer}" / str(steps)
-        (run_dir / "checkpoints").mkdir(parents=True, exist_ok=True)
-        return run_dir
+        run = self.base_dir.joinpath(model_name, f"layer{layer}", f"{steps}")
+        run.joinpath("checkpoints").mkdir(parents=True, exist_ok=True)
+        return run
 
+    # -- writers -------------------------------------------------------------------------------------------
     def save_checkpoint(self, experiment_dir: Path, model: torch.nn.Module, config: Dict[str, Any], step: int,
                         metrics: Optional[Dict[str, Any]] = None, is_final: bool = False,
                         extra: Optional[Dict[str, Any]] = None) -> None:
-        ckpt_dir = Path(experiment_dir) / "checkpoints"
-        ckpt_dir.mkdir(exist_ok=True)
-        name = "final" if is_final else f"step_{step}"
-        # contiguous row-major tensors on save: byte-identical layout to a reference checkpoint
-        state = {k: v.detach().contiguous() for k, v in model.state_dict().items()}
-        torch.save(state, ckpt_dir / f"{name}.pt")
+        run = Path(experiment_dir)
+        stem = "final" if is_final else f"step_{step}"
+        weights = run / "checkpoints" / f"{stem}.pt"
+        weights.parent.mkdir(exist_ok=True)
+        # contiguous row-major tensors: the file is laid out byte for byte like a reference checkpoint
+        torch.save({name: t.detach().contiguous() for name, t in model.state_dict().items()}, weights)
         if extra is None and hasattr(model, "num_batches_not_active"):
-            extra = {"num_batches_not_active": model.num_batches_not_active.detach().clone(), "step": step}
+            extra = {"step": step, "num_batches_not_active": model.num_batches_not_active.detach().clone()}
         if extra:
-            torch.save(extra, ckpt_dir / f"{name}.extra.pt")
-        cfg = _jsonable(dict(config))
+            torch.save(extra, weights.with_name(f"{stem}.extra.pt"))
+        cfg_out = dict(config)
+        cfg_out.pop("completed_at", None)
         if is_final:
-            cfg["completed_at"] = datetime.now(timezone.utc).replace(tzinfo=None).isoformat() + "Z"
-        else:
-            cfg.pop("completed_at", None)
-        with (Path(experiment_dir) / "config.json").open("w", encoding="utf-8") as f:
-            json.dump(cfg, f, indent=2)
+            stamp = datetime.now(timezone.utc).replace(tzinfo=None).isoformat()
+            cfg_out["completed_at"] = f"{stamp}Z"
+        _dump(run / "config.json", cfg_out)
         if metrics:
-            if is_final:
-                path = Path(experiment_dir) / "metrics.json"
-            else:
-                (Path(experiment_dir) / "metrics").mkdir(exist_ok=True)
-                path = Path(experiment_dir) / "metrics" / f"step_{step}.json"
-            with path.open("w", encoding="utf-8") as f:
-                json.dump(_jsonable(metrics), f, indent=2)
+            _dump(run / "metrics.json" if is_final else run / "metrics" / f"step_{step}.json", metrics)
 
     def save_activation_samples(self, experiment_dir: Path, sample_collector: Any, top_k_features: int = 100,
                                 samples_per_feature: int = 10) -> None:
         """clean_results.py:88-97: {run}/activation_samples/feature_%05d_samples.json + collection_summary.json."""
-        samples_dir = Path(experiment_dir) / "activation_samples"
-        samples_dir.mkdir(exist_ok=True)
-        sample_collector.save_samples(str(samples_dir), top_k_features, samples_per_feature)
+        target = Path(experiment_dir, "activation_samples")
+        target.mkdir(exist_ok=True)
+        sample_collector.save_samples(str(target), top_k_features, samples_per_feature)
 
+    # -- readers -------------------------------------------------------------------------------------------
     def list_experiments(self, model_name: Optional[str] = None, layer: Optional[int] = None) -> Dict[str, Any]:
         found: Dict[str, Any] = {}
         for mdir in sorted(p for p in self.base_dir.iterdir() if p.is_dir()):

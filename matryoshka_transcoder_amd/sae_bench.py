@@ -106,24 +106,28 @@ def _norm_decoder_rows(weights: torch.Tensor) -> torch.Tensor:
 
 
 def _coerce_matrix(array: np.ndarray, *, expected: Tuple[int, int], name: str) -> np.ndarray:
-    if array.shape == tuple(expected):
-        return array
-    if array.shape == tuple(expected)[::-1]:
-        return array.T
-    raise ValueError(f"Unexpected shape for {name}: {array.shape} (expected {expected} or {expected[::-1]})")
+    """[rows, cols] as given, or the transpose of a [cols, rows] array."""
+    want = tuple(expected)
+    if array.shape != want and array.shape != want[::-1]:
+        raise ValueError(f"Unexpected shape for {name}: {array.shape} (expected {want} or {want[::-1]})")
+    return array if array.shape == want else array.T
 
 
 def _coerce_vector(array: np.ndarray, *, expected: int, name: str) -> np.ndarray:
-    if array.shape in ((expected,), (expected, 1), (1, expected)):
-        return array.reshape(-1)
-    raise ValueError(f"Unexpected shape for {name}: {array.shape} (expected {(expected,)})")
+    """[n], [n, 1] or [1, n] -> [n]."""
+    if array.shape not in ((expected,), (expected, 1), (1, expected)):
+        raise ValueError(f"Unexpected shape for {name}: {array.shape} (expected {(expected,)})")
+    return array.reshape(-1)
 
 
 def _closed_prefixes(prefix_sizes, dict_size: int) -> list:
-    p = list(prefix_sizes) if prefix_sizes else [dict_size]
-    if p[-1] != dict_size:
-        p.append(dict_size)
-    return p
+    """One group by default; the dictionary size is appended when the list stops short of it."""
+    out = list(prefix_sizes or [dict_size])
+    return out if out[-1] == dict_size else out + [dict_size]
+
+
+def _valid_top_k(top_k: int, dict_size: int) -> int:
+    return top_k if 0 < top_k <= dict_size else dict_size
 
 
 # ------------------------------------------------------------------ adapters
@@ -131,26 +135,25 @@ class MatryoshkaAutoInterpAdapter(MatryoshkaTranscoder):
     """`MatryoshkaTranscoder` + the attributes SAEBench expects on an SAE (wrappers.py:53-109)."""
 
     def __init__(self, cfg: dict, *, sae_cfg: AutoInterpSAEConfig) -> None:
-        c = copy.deepcopy(dict(cfg))
-        D = int(c["dict_size"])
-        c["prefix_sizes"] = _closed_prefixes(c.get("prefix_sizes"), D)
-        k = int(c.get("top_k", D))
-        c["top_k"] = D if (k <= 0 or k > D) else k
-        c["top_k_aux"] = max(int(c.get("top_k_aux", c["top_k"] * 2)), c["top_k"])
-        c.setdefault("n_batches_to_dead", 20)
-        super().__init__(c)
+        own = copy.deepcopy(dict(cfg))
+        width = int(own["dict_size"])
+        own["prefix_sizes"] = _closed_prefixes(own.get("prefix_sizes"), width)
+        own["top_k"] = _valid_top_k(int(own.get("top_k", width)), width)
+        own["top_k_aux"] = max(own["top_k"], int(own.get("top_k_aux", 2 * own["top_k"])))
+        own.setdefault("n_batches_to_dead", 20)
+        super().__init__(own)
         self.cfg = sae_cfg
-        self.device = torch.device(c["device"])
-        self._sae_dtype = c["dtype"]
-        self.to(device=self.device, dtype=c["dtype"])
+        self.device = torch.device(own["device"])
+        self._sae_dtype = own["dtype"]
+        self.to(device=self.device, dtype=own["dtype"])
 
     def to(self, *args, **kwargs):
-        module = super().to(*args, **kwargs)
-        if "device" in kwargs:
-            self.device = torch.device(kwargs["device"])
+        moved = super().to(*args, **kwargs)
         if "dtype" in kwargs:
             self._sae_dtype = kwargs["dtype"]
-        return module
+        if "device" in kwargs:
+            self.device = torch.device(kwargs["device"])
+        return moved
 
     def get_decoder_row_norms(self) -> torch.Tensor:
         return self.W_dec.detach().norm(dim=-1)
@@ -158,88 +161,79 @@ class MatryoshkaAutoInterpAdapter(MatryoshkaTranscoder):
     @torch.no_grad()
     def validate_reconstruction(self, source_acts: torch.Tensor, target_acts: torch.Tensor) -> ReconstructionReport:
         """encode -> decode -> MSE (model dtype), FVU (fp32), mean |feature| (wrappers.py:100-109)."""
-        encoded = self.encode(source_acts)
-        decoded = self.decode(encoded)
-        mse = torch.nn.functional.mse_loss(decoded, target_acts).item()
-        fvu = compute_fvu(target_acts, decoded)
-        return ReconstructionReport(fvu=float(fvu), mse=mse, mean_activation=encoded.abs().mean().item())
+        features = self.encode(source_acts)
+        recon = self.decode(features)
+        return ReconstructionReport(fvu=float(compute_fvu(target_acts, recon)),
+                                    mse=torch.nn.functional.mse_loss(recon, target_acts).item(),
+                                    mean_activation=features.abs().mean().item())
+
+    def _renormalise_decoder(self):
+        with torch.no_grad():
+            self.W_dec.data = _norm_decoder_rows(self.W_dec.data)
 
 
 def build_matryoshka_adapter(cfg: Mapping[str, Any], *, state_dict_path=None, hook_layer: Optional[int] = None,
                              hook_point: Optional[str] = None) -> MatryoshkaAutoInterpAdapter:
     """wrappers.py:118-156: adapter from a training config (+ optionally a saved state_dict); decoder rows are
     re-normalised after loading."""
-    c = copy.deepcopy(dict(cfg))
-    if hook_layer is None:
-        hook_layer = c.get("source_layer", c["layer"])
-    if hook_point is None:
-        hook_point = c.get("source_hook_point") or get_hook_name(c["source_site"], hook_layer, c["model_name"])
+    own = copy.deepcopy(dict(cfg))
+    layer = own.get("source_layer", own["layer"]) if hook_layer is None else hook_layer
+    point = hook_point or own.get("source_hook_point") or get_hook_name(own["source_site"], layer, own["model_name"])
     sae_cfg = AutoInterpSAEConfig.from_kwargs(
-        model_name=c["model_name"], hook_layer=hook_layer, hook_name=hook_point,
-        d_in=c.get("source_act_size", c.get("act_size")), d_sae=c["dict_size"], dtype=c["dtype"],
-        device=torch.device(c["device"]), context_size=c.get("seq_len"), dataset_path=c.get("dataset_path", ""))
-    adapter = MatryoshkaAutoInterpAdapter(c, sae_cfg=sae_cfg)
+        model_name=own["model_name"], hook_layer=layer, hook_name=point, d_sae=own["dict_size"],
+        d_in=own.get("source_act_size", own.get("act_size")), dtype=own["dtype"], device=torch.device(own["device"]),
+        context_size=own.get("seq_len"), dataset_path=own.get("dataset_path", ""))
+    adapter = MatryoshkaAutoInterpAdapter(own, sae_cfg=sae_cfg)
     if state_dict_path is not None:
-        state = torch.load(Path(state_dict_path), map_location=adapter.device, weights_only=True)
-        adapter.load_state_dict(state, strict=False)
-    with torch.no_grad():
-        adapter.W_dec.data = _norm_decoder_rows(adapter.W_dec.data)
+        adapter.load_state_dict(torch.load(Path(state_dict_path), map_location=adapter.device, weights_only=True),
+                                strict=False)
+    adapter._renormalise_decoder()
     return adapter
 
 
 class NPZTranscoderAdapter(MatryoshkaAutoInterpAdapter):
     """Cross-layer transcoder from a `.npz` checkpoint (wrappers.py:159-242)."""
 
+    # parameter -> (other accepted key, matrix shape as spec attributes or vector length attribute)
+    _ARRAYS = (("W_enc", "encoder.W", ("d_in", "d_sae")), ("W_dec", "decoder.W", ("d_sae", "d_out")),
+               ("b_enc", "encoder.b", "d_sae"), ("b_dec", "decoder.b", "d_out"))
+
     def __init__(self, *, spec: NPZTranscoderSpec):
-        dtype = getattr(torch, spec.dtype)
-        D = int(spec.d_sae)
-        k = spec.top_k if spec.top_k is not None else min(512, D)
-        cfg = {
-            "seed": 0, "act_size": spec.d_in,                 # absent in the reference's dict (see module docstring)
-            "model_name": spec.model_name, "device": spec.device, "dtype": dtype, "dict_size": D,
-            "source_act_size": spec.d_in, "target_act_size": spec.d_out,
-            "top_k": D if (k <= 0 or k > D) else k, "prefix_sizes": _closed_prefixes(spec.prefix_sizes, D),
-            "aux_penalty": spec.aux_penalty or 0.0, "layer": spec.source_layer, "source_layer": spec.source_layer,
-            "target_layer": spec.target_layer or spec.source_layer,
-            "source_site": spec.source_hook_point.split(".")[-1], "target_site": spec.target_hook_point.split(".")[-1],
-            "seq_len": 128,
-        }
-        sae_cfg = AutoInterpSAEConfig.from_kwargs(model_name=spec.model_name, hook_layer=spec.source_layer,
-                                                  hook_name=spec.source_hook_point, d_in=spec.d_in, d_sae=spec.d_sae,
-                                                  dtype=dtype, device=torch.device(spec.device))
-        super().__init__(cfg, sae_cfg=sae_cfg)
+        dtype, width = getattr(torch, spec.dtype), int(spec.d_sae)
+        site = lambda hook: hook.split(".")[-1]                      # noqa: E731
+        cfg = dict(
+            seed=0, act_size=spec.d_in,                              # absent in the reference's dict (module docstring)
+            model_name=spec.model_name, dtype=dtype, device=spec.device, dict_size=width,
+            source_act_size=spec.d_in, target_act_size=spec.d_out,
+            prefix_sizes=_closed_prefixes(spec.prefix_sizes, width),
+            top_k=_valid_top_k(min(512, width) if spec.top_k is None else spec.top_k, width),
+            aux_penalty=spec.aux_penalty or 0.0, seq_len=128,
+            layer=spec.source_layer, source_layer=spec.source_layer, target_layer=spec.target_layer or spec.source_layer,
+            source_site=site(spec.source_hook_point), target_site=site(spec.target_hook_point))
+        super().__init__(cfg, sae_cfg=AutoInterpSAEConfig.from_kwargs(
+            model_name=spec.model_name, hook_layer=spec.source_layer, hook_name=spec.source_hook_point, d_in=spec.d_in,
+            d_sae=spec.d_sae, dtype=dtype, device=torch.device(spec.device)))
         self.spec = spec
         self.load_npz_weights(spec)
-        with torch.no_grad():
-            self.W_dec.data = _norm_decoder_rows(self.W_dec.data)
+        self._renormalise_decoder()
 
     def load_npz_weights(self, spec: NPZTranscoderSpec) -> None:
-        path = Path(spec.path)
-        if not path.exists():
-            raise FileNotFoundError(f"Transcoder checkpoint not found: {path}")
-        data = np.load(path)                                  # allow_pickle stays False
-
-        def fetch(names: Iterable[str]) -> np.ndarray:
-            names = list(names)
-            for n in names:
-                if n in data:
-                    return data[n]
-            raise KeyError(f"Unable to find any of {names} in {path.name}")
-
-        km = spec.weight_key_map
-        W_enc = _coerce_matrix(fetch([km.get("W_enc", "W_enc"), "W_enc", "encoder.W"]),
-                               expected=(spec.d_in, spec.d_sae), name="W_enc")
-        W_dec = _coerce_matrix(fetch([km.get("W_dec", "W_dec"), "W_dec", "decoder.W"]),
-                               expected=(spec.d_sae, spec.d_out), name="W_dec")
-        b_enc = _coerce_vector(fetch([km.get("b_enc", "b_enc"), "b_enc", "encoder.b"]), expected=spec.d_sae, name="b_enc")
-        b_dec = _coerce_vector(fetch([km.get("b_dec", "b_dec"), "b_dec", "decoder.b"]), expected=spec.d_out, name="b_dec")
-        dev, dt = self.device, self.W_dec.dtype
-        with torch.no_grad():
-            # W_enc keeps its feature-major storage: copy_ into the [A_s, D] view transposes on the fly
-            self.W_enc.data.copy_(torch.from_numpy(np.ascontiguousarray(W_enc)).to(device=dev, dtype=dt))
-            self.W_dec.data.copy_(torch.from_numpy(np.ascontiguousarray(W_dec)).to(device=dev, dtype=dt))
-            self.b_enc.data.copy_(torch.from_numpy(np.ascontiguousarray(b_enc)).to(device=dev, dtype=dt))
-            self.b_dec.data.copy_(torch.from_numpy(np.ascontiguousarray(b_dec)).to(device=dev, dtype=dt))
+        ckpt = Path(spec.path)
+        if not ckpt.exists():
+            raise FileNotFoundError(f"Transcoder checkpoint not found: {ckpt}")
+        stored = np.load(ckpt)                                        # allow_pickle stays False
+        for param, alias, shape in self._ARRAYS:
+            keys = [spec.weight_key_map.get(param, param), param, alias]
+            hit = next((k for k in keys if k in stored), None)
+            if hit is None:
+                raise KeyError(f"Unable to find any of {keys} in {ckpt.name}")
+            if isinstance(shape, tuple):
+                arr = _coerce_matrix(stored[hit], expected=tuple(getattr(spec, a) for a in shape), name=param)
+            else:
+                arr = _coerce_vector(stored[hit], expected=getattr(spec, shape), name=param)
+            target = getattr(self, param)
+            with torch.no_grad():      # W_enc keeps its feature-major storage: copy_ into the [A_s, D] view transposes
+                target.data.copy_(torch.from_numpy(np.ascontiguousarray(arr)).to(device=self.device, dtype=target.dtype))
 
 
 def build_npz_transcoder_adapter(spec: NPZTranscoderSpec) -> NPZTranscoderAdapter:
