@@ -27,7 +27,7 @@ def main():
     from matryoshka_transcoder_amd.transcoder import MatryoshkaTranscoder
     variants = [("gpt2", False), ("gpt2", False), ("gpt2-noaux", False), ("gemma2-2b", False)]
     if args.dist:
-        variants += [("gpt2-noaux", True), ("gemma2-2b", True)]
+        variants += [("gpt2-noaux", True), ("gpt2", True), ("gpt2", True), ("gemma2-2b", True)]
     for wl, sharded in variants:
         cfg, B = bench.make_cfg(wl.replace("-noaux", ""), torch.bfloat16, "cuda:0")
         if wl.endswith("-noaux"):
