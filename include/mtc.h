@@ -135,18 +135,6 @@ int mtc_select_global_topk_carry(const mtc_desc* d, const void* acts, uint32_t k
                                  mtc_select_state* st, int32_t* row_ptr, int32_t* col_idx,
                                  void* vals, void* stream);
 
-/* The same select with the candidate pass folded into the encoder: mtc_encode_fwd_collect is mtc_encode_fwd whose
- * epilogue also appends every activation >= the carried bound to the per-row candidate lists inside the select's
- * workspace (same `carry` and `workspace` as here; it clears the row counts itself), so the [B][D] activations are not
- * read again on the common path; mtc_select_global_topk_collected then only puts each row's candidates in column order
- * and runs the exact select on them.  Identical results; a wrong bound / overflowing row falls back to the full-size
- * passes over acts exactly as mtc_select_global_topk_carry does.  (sae.py:173-187 in two launches' worth of traffic.) */
-int mtc_encode_fwd_collect(const mtc_desc* d, const void* x, const void* W_encT, const void* b_enc, void* acts,
-                           const uint32_t* carry, void* select_workspace, size_t select_workspace_bytes, void* stream);
-int mtc_select_global_topk_collected(const mtc_desc* d, const void* acts, uint32_t k_total, void* workspace,
-                                     size_t workspace_bytes, uint32_t* carry, mtc_select_state* st, int32_t* row_ptr,
-                                     int32_t* col_idx, void* vals, void* stream);
-
 /* Helpers of the feature-sharded caller (no counterpart in the single-process reference; each replaces a
  * handful of tiny tensor ops between two collectives):
  *   mtc_select_offsets_sharded : mtc_select_offsets with the tie order of a sharded dictionary -- ties are

@@ -114,32 +114,4 @@ template <> __device__ __forceinline__ uint32_t key_of<MTC_F32>(const void* acts
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
-// Where the encoder's epilogue drops the candidates of the carried-bound select (select.hip): per batch row a list of
-// up to C (value, column) pairs in arrival order + the row's count (which keeps counting past C: that is the
-// overflow signal).  cnt == nullptr: nothing is collected.
-struct CandOut {
-    const uint32_t* carry;      // carry[0] = bit pattern of the lower bound (0 = none yet)
-    void* vals;                 // [B][C] model dtype
-    int32_t* cols;              // [B][C]
-    uint32_t* cnt;              // [B]
-    int C;
-};
-int carry_layout(const mtc_desc* d, void* workspace, size_t workspace_bytes, CandOut* out);   // select.hip
-
-template <int DT>
-__device__ __forceinline__ void emit_candidates(const CandOut& co, uint32_t guess, int b, int f, const float (&p)[4]) {
-    typedef typename DType<DT>::T T;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const uint32_t k = __float_as_uint(p[r]);
-        if (k >= guess && k <= 0x7f800000u) {
-            const uint32_t pos = atomicAdd(co.cnt + b, 1u);
-            if (pos < (uint32_t)co.C) {
-                DType<DT>::st(reinterpret_cast<T*>(co.vals) + (size_t)b * co.C + pos, p[r]);
-                co.cols[(size_t)b * co.C + pos] = f + r;
-            }
-        }
-    }
-}
-
 }  // namespace mtc

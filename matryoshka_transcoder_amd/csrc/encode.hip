@@ -119,74 +119,9 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-// Epilogue of the bf16 MFMA kernels: lane holds features f = fbase + i*16 + r (r = 0..3) of batch rows b = bbase + j*16.
-// round -> + b_enc -> round -> ReLU / threshold, 8-byte stores.  With a collecting select (guess != 0) every value >=
-// the carried bound is also appended to its batch row's candidate list.  Appending needs a slot from the row's
-// counter; an atomic whose result is awaited inside the store loop costs a memory round trip per hit (measured: +0.09 ms
-// on the encoder), so the loop only records hits in a bit mask per batch row, then ONE atomicAdd per (lane, row)
-// reserves the slots for all of them -- the four are in flight together -- and a second sweep writes the pairs.
-template <int NI>
-__device__ __forceinline__ void bf16_epilogue(const f32x4 (&acc)[NI][4], const u16* __restrict__ bias, u16* __restrict__ acts,
-                                              int M, int N, int fbase, int bbase, float fl, uint32_t guess, const CandOut& co) {
-    uint32_t hit[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        const int f = fbase + i * 16;
-        if (f >= N) continue;
-        const uint2 bb = *reinterpret_cast<const uint2*>(bias + f);     // N % 8 == 0 -> in bounds, aligned
-        const float bv[4] = {bf16_bits_to_f32(bb.x & 0xffffu), bf16_bits_to_f32(bb.x >> 16),
-                             bf16_bits_to_f32(bb.y & 0xffffu), bf16_bits_to_f32(bb.y >> 16)};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int b = bbase + j * 16;
-            if (b >= M) continue;
-            const f32x4 v = acc[i][j];
-            float p[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float pre = round_bf16(round_bf16(v[r]) + bv[r]);
-                p[r] = pre > fl ? pre : 0.f;                             // ReLU / threshold, never -0.0
-                const uint32_t k = __float_as_uint(p[r]);
-                if (guess && k >= guess && k <= 0x7f800000u) hit[j] |= 1u << (i * 4 + r);
-            }
-            *reinterpret_cast<uint2*>(acts + (size_t)b * N + f) = relu_pack4(p[0], p[1], p[2], p[3], 0.f);
-        }
-    }
-    if (!guess) return;
-    uint32_t slot[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const uint32_t n = (uint32_t)__popc(hit[j]);
-        slot[j] = n ? atomicAdd(co.cnt + (bbase + j * 16), n) : 0u;      // hit[j] != 0 implies the row is inside M
-    }
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        const int f = fbase + i * 16;
-        if (((hit[0] | hit[1] | hit[2] | hit[3]) >> (i * 4) & 0xfu) == 0u) continue;
-        const uint2 bb = *reinterpret_cast<const uint2*>(bias + f);
-        const float bv[4] = {bf16_bits_to_f32(bb.x & 0xffffu), bf16_bits_to_f32(bb.x >> 16),
-                             bf16_bits_to_f32(bb.y & 0xffffu), bf16_bits_to_f32(bb.y >> 16)};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if ((hit[j] >> (i * 4) & 0xfu) == 0u) continue;
-            const size_t rowbase = (size_t)(bbase + j * 16) * co.C;
-            const f32x4 v = acc[i][j];
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (hit[j] >> (i * 4 + r) & 1u) {
-                    const uint32_t pos = slot[j]++;
-                    if (pos < (uint32_t)co.C) {
-                        reinterpret_cast<u16*>(co.vals)[rowbase + pos] = (u16)f32_to_bf16_bits(round_bf16(round_bf16(v[r]) + bv[r]));
-                        co.cols[rowbase + pos] = f + r;
-                    }
-                }
-        }
-    }
-}
-
 __global__ __launch_bounds__(256, 2) void encode_bf16_mfma_kernel(const u16* __restrict__ X, const u16* __restrict__ Wt,
                                                                   const u16* __restrict__ bias, u16* __restrict__ acts,
-                                                                  int M, int N, int K, int mt, int nt, const void* __restrict__ thr, CandOut co) {
+                                                                  int M, int N, int K, int mt, int nt, const void* __restrict__ thr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // layout: [stage][operand(0 = X, 1 = W)][128 rows][128 B]
     int tm, tn;
@@ -263,8 +198,23 @@ __global__ __launch_bounds__(256, 2) void encode_bf16_mfma_kernel(const u16* __r
     const int fbase = col0 + wf * 64 + fq * 4;
     const int bbase = row0 + wb * 64 + fr;
     const float fl = epilogue_floor<MTC_BF16>(thr);
-    const uint32_t guess = co.cnt ? co.carry[0] : 0u;
-    bf16_epilogue<4>(acc, bias, acts, M, N, fbase, bbase, fl, guess, co);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = fbase + i * 16;
+        if (f >= N) continue;
+        const uint2 bb = *reinterpret_cast<const uint2*>(bias + f);     // N % 8 == 0 -> in bounds, aligned
+        const float b0 = bf16_bits_to_f32(bb.x & 0xffffu), b1 = bf16_bits_to_f32(bb.x >> 16);
+        const float b2 = bf16_bits_to_f32(bb.y & 0xffffu), b3 = bf16_bits_to_f32(bb.y >> 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int b = bbase + j * 16;
+            if (b >= M) continue;
+            const f32x4 v = acc[i][j];
+            *reinterpret_cast<uint2*>(acts + (size_t)b * N + f) =
+                relu_pack4(round_bf16(round_bf16(v[0]) + b0), round_bf16(round_bf16(v[1]) + b1),
+                           round_bf16(round_bf16(v[2]) + b2), round_bf16(round_bf16(v[3]) + b3), fl);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------- K1 fp32 MFMA
@@ -276,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void encode_bf16_mfma_kernel(const u16* __r
 constexpr int BK32 = 32;
 __global__ __launch_bounds__(256, 2) void encode_f32_mfma_kernel(const float* __restrict__ X, const float* __restrict__ Wt,
                                                                  const float* __restrict__ bias, float* __restrict__ acts,
-                                                                 int M, int N, int K, int mt, int nt, const void* __restrict__ thr, CandOut co) {
+                                                                 int M, int N, int K, int mt, int nt, const void* __restrict__ thr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int tm, tn;
     xcd_tile_coords(blockIdx.x, mt * nt, mt, nt, tm, tn);
@@ -349,7 +299,6 @@ __global__ __launch_bounds__(256, 2) void encode_f32_mfma_kernel(const float* __
     const int fbase = col0 + wf * 64 + fq * 4;
     const int bbase = row0 + wb * 64 + fr;
     const float fl = epilogue_floor<MTC_F32>(thr);
-    const uint32_t guess = co.cnt ? co.carry[0] : 0u;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int f = fbase + i * 16;
@@ -360,11 +309,9 @@ __global__ __launch_bounds__(256, 2) void encode_f32_mfma_kernel(const float* __
             const int b = bbase + j * 16;
             if (b >= M) continue;
             f32x4 v = acc[i][j];
-            float p[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { const float pre = v[r] + bb[r]; p[r] = pre > fl ? pre : 0.f; v[r] = p[r]; }
+            for (int r = 0; r < 4; ++r) { const float pre = v[r] + bb[r]; v[r] = pre > fl ? pre : 0.f; }
             *reinterpret_cast<f32x4*>(acts + (size_t)b * N + f) = v;
-            if (guess) emit_candidates<MTC_F32>(co, guess, b, f, p);
         }
     }
 }
@@ -425,7 +372,7 @@ __device__ __forceinline__ void mfma_quadrant(bf16x8 (&wf)[2][4], bf16x8 (&xf)[2
 
 __global__ __launch_bounds__(512, 1) void encode_bf16_mfma256_kernel(const u16* __restrict__ X, const u16* __restrict__ Wt,
                                                                      const u16* __restrict__ bias, u16* __restrict__ acts,
-                                                                     int M, int N, int K, int mt, int nt, const void* __restrict__ thr, CandOut co) {
+                                                                     int M, int N, int K, int mt, int nt, const void* __restrict__ thr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int tm, tn;
     xcd_tile_coords(blockIdx.x, mt * nt, mt, nt, tm, tn);
@@ -537,8 +484,23 @@ __global__ __launch_bounds__(512, 1) void encode_bf16_mfma256_kernel(const u16* 
     const int fbase = col0 + wr * 128 + fq * 4;
     const int bbase = row0 + wc * 64 + fr;
     const float fl = epilogue_floor<MTC_BF16>(thr);
-    const uint32_t guess = co.cnt ? co.carry[0] : 0u;
-    bf16_epilogue<8>(acc, bias, acts, M, N, fbase, bbase, fl, guess, co);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int f = fbase + i * 16;
+        if (f >= N) continue;
+        const uint2 bb = *reinterpret_cast<const uint2*>(bias + f);
+        const float b0 = bf16_bits_to_f32(bb.x & 0xffffu), b1 = bf16_bits_to_f32(bb.x >> 16);
+        const float b2 = bf16_bits_to_f32(bb.y & 0xffffu), b3 = bf16_bits_to_f32(bb.y >> 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int b = bbase + j * 16;
+            if (b >= M) continue;
+            const f32x4 v = acc[i][j];
+            *reinterpret_cast<uint2*>(acts + (size_t)b * N + f) =
+                relu_pack4(round_bf16(round_bf16(v[0]) + b0), round_bf16(round_bf16(v[1]) + b1),
+                           round_bf16(round_bf16(v[2]) + b2), round_bf16(round_bf16(v[3]) + b3), fl);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------- K1 generic
@@ -547,7 +509,7 @@ __global__ __launch_bounds__(512, 1) void encode_bf16_mfma256_kernel(const u16* 
 template <int DT>
 __global__ __launch_bounds__(256) void encode_generic_kernel(const void* __restrict__ X, const void* __restrict__ Wt,
                                                              const void* __restrict__ bias, void* __restrict__ acts,
-                                                             int M, int N, int K, const void* __restrict__ thr, CandOut co) {
+                                                             int M, int N, int K, const void* __restrict__ thr) {
     typedef DType<DT> D_;
     typedef typename D_::T T;
     __shared__ float xs[16][64 + 4];
@@ -581,7 +543,6 @@ __global__ __launch_bounds__(256) void encode_generic_kernel(const void* __restr
     T* out = reinterpret_cast<T*>(acts);
     const T* bp = reinterpret_cast<const T*>(bias);
     const float fl = epilogue_floor<DT>(thr);
-    const uint32_t guess = co.cnt ? co.carry[0] : 0u;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = row0 + ty * 4 + i;
@@ -591,15 +552,7 @@ __global__ __launch_bounds__(256) void encode_generic_kernel(const void* __restr
             const int c = col0 + tx * 4 + j;
             if (c >= N) continue;
             const float pre = D_::rnd(D_::rnd(acc[i][j]) + D_::ld(bp + c));
-            const float pv = pre > fl ? pre : 0.f;
-            D_::st(out + (size_t)r * N + c, pv);
-            if (guess) {
-                const uint32_t kb = __float_as_uint(pv);
-                if (kb >= guess && kb <= 0x7f800000u) {
-                    const uint32_t pos = atomicAdd(co.cnt + r, 1u);
-                    if (pos < (uint32_t)co.C) { D_::st(reinterpret_cast<T*>(co.vals) + (size_t)r * co.C + pos, pv); co.cols[(size_t)r * co.C + pos] = c; }
-                }
-            }
+            D_::st(out + (size_t)r * N + c, pre > fl ? pre : 0.f);
         }
     }
 }
@@ -622,7 +575,7 @@ extern "C" int mtc_row_normalize(const mtc_desc* d, const void* x, void* x_norm,
 }
 
 static int encode_impl(const mtc_desc* d, const void* x, const void* W_encT, const void* b_enc, const void* thr,
-                       void* acts, void* stream, CandOut co = CandOut{nullptr, nullptr, nullptr, nullptr, 0}) {
+                       void* acts, void* stream) {
     const int M = d->B, N = d->D, K = d->A_s;
     if (d->dtype == MTC_F32 && (K % BK32) == 0 && !(getenv("MTC_ENCODE_F32_GENERIC"))) {
         const int lds = 2 * 2 * TILE_BYTES;
@@ -630,7 +583,7 @@ static int encode_impl(const mtc_desc* d, const void* x, const void* W_encT, con
         const int mt = (M + BM - 1) / BM, nt = (N + BN - 1) / BN;
         hipLaunchKernelGGL(encode_f32_mfma_kernel, dim3(mt * nt), dim3(256), lds, as_stream(stream),
                            reinterpret_cast<const float*>(x), reinterpret_cast<const float*>(W_encT),
-                           reinterpret_cast<const float*>(b_enc), reinterpret_cast<float*>(acts), M, N, K, mt, nt, thr, co);
+                           reinterpret_cast<const float*>(b_enc), reinterpret_cast<float*>(acts), M, N, K, mt, nt, thr);
         return check_launch("mtc_encode_fwd");
     }
     const char* force = getenv("MTC_ENCODE_TILE");
@@ -641,20 +594,20 @@ static int encode_impl(const mtc_desc* d, const void* x, const void* W_encT, con
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         const int mt = (M + B2M - 1) / B2M, nt = (N + B2N - 1) / B2N;
         hipLaunchKernelGGL(encode_bf16_mfma256_kernel, dim3(mt * nt), dim3(512), lds, as_stream(stream),
-                           (const u16*)x, (const u16*)W_encT, (const u16*)b_enc, (u16*)acts, M, N, K, mt, nt, thr, co);
+                           (const u16*)x, (const u16*)W_encT, (const u16*)b_enc, (u16*)acts, M, N, K, mt, nt, thr);
     } else if (d->dtype == MTC_BF16 && (K % BK) == 0) {
         const int lds = 2 * 2 * TILE_BYTES;
         hipFuncSetAttribute(reinterpret_cast<const void*>(encode_bf16_mfma_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         const int mt = (M + BM - 1) / BM, nt = (N + BN - 1) / BN;
         hipLaunchKernelGGL(encode_bf16_mfma_kernel, dim3(mt * nt), dim3(256), lds, as_stream(stream),
-                           (const u16*)x, (const u16*)W_encT, (const u16*)b_enc, (u16*)acts, M, N, K, mt, nt, thr, co);
+                           (const u16*)x, (const u16*)W_encT, (const u16*)b_enc, (u16*)acts, M, N, K, mt, nt, thr);
     } else {
         const dim3 grid((N + 63) / 64, (M + 63) / 64), block(256);
         if (d->dtype == MTC_BF16)
-            hipLaunchKernelGGL(encode_generic_kernel<MTC_BF16>, grid, block, 0, as_stream(stream), x, W_encT, b_enc, acts, M, N, K, thr, co);
+            hipLaunchKernelGGL(encode_generic_kernel<MTC_BF16>, grid, block, 0, as_stream(stream), x, W_encT, b_enc, acts, M, N, K, thr);
         else
-            hipLaunchKernelGGL(encode_generic_kernel<MTC_F32>, grid, block, 0, as_stream(stream), x, W_encT, b_enc, acts, M, N, K, thr, co);
+            hipLaunchKernelGGL(encode_generic_kernel<MTC_F32>, grid, block, 0, as_stream(stream), x, W_encT, b_enc, acts, M, N, K, thr);
     }
     return check_launch("mtc_encode_fwd");
 }
@@ -664,21 +617,6 @@ extern "C" int mtc_encode_fwd(const mtc_desc* d, const void* x, const void* W_en
     if (check_desc(d, "mtc_encode_fwd")) return -1;
     MTC_REQUIRE(x && W_encT && b_enc && acts, "mtc_encode_fwd: null pointer");
     return encode_impl(d, x, W_encT, b_enc, nullptr, acts, stream);
-}
-
-extern "C" int mtc_encode_fwd_collect(const mtc_desc* d, const void* x, const void* W_encT, const void* b_enc, void* acts,
-                                      const uint32_t* carry, void* select_workspace, size_t select_workspace_bytes,
-                                      void* stream) {
-    if (check_desc(d, "mtc_encode_fwd_collect")) return -1;
-    MTC_REQUIRE(x && W_encT && b_enc && acts && carry && select_workspace, "mtc_encode_fwd_collect: null pointer");
-    CandOut co;
-    if (carry_layout(d, select_workspace, select_workspace_bytes, &co)) return -1;
-    co.carry = carry;
-    if (hipMemsetAsync(co.cnt, 0, (size_t)d->B * sizeof(uint32_t), as_stream(stream)) != hipSuccess) {
-        set_error("mtc_encode_fwd_collect: memset failed");
-        return -2;
-    }
-    return encode_impl(d, x, W_encT, b_enc, nullptr, acts, stream, co);
 }
 
 extern "C" int mtc_encode_threshold_infer(const mtc_desc* d, const void* x, const void* W_encT, const void* b_enc,

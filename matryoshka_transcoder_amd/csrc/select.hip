@@ -576,43 +576,6 @@ __global__ __launch_bounds__(256) void select_candidates_kernel(const void* __re
     if (lane == 0) cand_cnt[row] = out;
 }
 
-// Candidates collected by the ENCODER's epilogue (mtc_encode_fwd_collect) arrive per row in whatever order the tiles
-// finished; the select wants them in ascending column order (ties are granted by ascending flat index) with the unused
-// tail of the row zeroed.  Wave per row, rank by counting on the (unique) columns through LDS.  Rows that overflowed
-// (count > C) are left alone: the verdict kernel sends such a batch down the full-size path.
-template <int DT>
-__global__ __launch_bounds__(256) void select_sort_candidates_kernel(int B, int C, const uint32_t* __restrict__ carry,
-                                                                     void* __restrict__ cand_vals, int32_t* __restrict__ cand_cols,
-                                                                     const uint32_t* __restrict__ cand_cnt) {
-    typedef typename DType<DT>::T T;
-    __shared__ int s_col[4][1024];
-    __shared__ T s_val[4][1024];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + w);
-    if (row >= B || carry[0] == 0) return;
-    const uint32_t cnt = cand_cnt[row];
-    if (cnt > (uint32_t)C) return;
-    const int n = (int)cnt;
-    T* vout = reinterpret_cast<T*>(cand_vals) + (size_t)row * C;
-    int32_t* cout = cand_cols + (size_t)row * C;
-    for (int i = lane; i < n; i += 64) { s_col[w][i] = cout[i]; s_val[w][i] = vout[i]; }
-    // the staging area belongs to this wave alone: LDS operations of one wave complete in order, so a fence for the
-    // compiler is all that is needed (a workgroup barrier would deadlock with the waves that returned above)
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    for (int i = lane; i < n; i += 64) {
-        const int c = s_col[w][i];
-        int rank = 0;
-        for (int j = 0; j < n; ++j) rank += s_col[w][j] < c ? 1 : 0;
-        cout[rank] = c;
-        vout[rank] = s_val[w][i];
-    }
-    const uint32_t al = ((uint32_t)n + 7u) & ~7u;
-    if ((uint32_t)n + lane < al) DType<DT>::st(vout + n + lane, 0.f);
-    const float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (uint32_t ch = (al >> 3) + lane; ch < (uint32_t)(C >> 3); ch += 64) store8<DT>(vout, (size_t)ch * 8, z);
-}
-
 // one workgroup, after the candidate pass: total / overflow from the per-row counts -> which path is valid
 // (also what mtc_select_init and the histogram memset do, to save two launches)
 __global__ __launch_bounds__(1024) void select_carry_decide_kernel(uint32_t* carry, const uint32_t* __restrict__ cand_cnt, int B, int C,
@@ -942,67 +905,34 @@ extern "C" size_t mtc_select_carry_workspace_bytes(const mtc_desc* d) {
            ((cells * sizeof(int32_t) + 255) & ~(size_t)255) + (size_t)d->B * sizeof(uint32_t);
 }
 
-namespace mtc {
-// pointers into the carried-bound select's workspace (shared with the encoder's collecting epilogue)
-struct CarryWs {
-    uint32_t *hist, *row_gt, *row_eq, *tie_take, *row_above, *row_sub, *cand_cnt;
-    char* cand_vals;
-    int32_t* cand_cols;
-    int C;
-};
-static CarryWs carry_ws(const mtc_desc* d, void* workspace) {
-    CarryWs w;
-    w.C = carry_cols(d);
-    const size_t es = d->dtype == MTC_BF16 ? 2 : 4;
-    char* ws = reinterpret_cast<char*>(workspace);
-    w.hist = reinterpret_cast<uint32_t*>(ws);
-    const size_t bpad = (size_t)((d->B + 63) & ~63);
-    w.row_gt = w.hist + 3 * HIST_BINS;
-    w.row_eq = w.row_gt + bpad;
-    w.tie_take = w.row_eq + bpad;
-    w.row_above = w.tie_take + bpad;
-    w.row_sub = w.row_above + bpad;
-    w.cand_vals = ws + ((mtc_select_workspace_bytes(d) + 255) & ~(size_t)255);
-    w.cand_cols = reinterpret_cast<int32_t*>(w.cand_vals + (((size_t)d->B * w.C * es + 255) & ~(size_t)255));
-    w.cand_cnt = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(w.cand_cols) +
-                                             (((size_t)d->B * w.C * sizeof(int32_t) + 255) & ~(size_t)255));
-    return w;
-}
-int carry_layout(const mtc_desc* d, void* workspace, size_t workspace_bytes, CandOut* out) {
-    if (workspace_bytes < mtc_select_carry_workspace_bytes(d)) {
-        set_error("carried-bound select workspace too small (%zu < %zu)", workspace_bytes, mtc_select_carry_workspace_bytes(d));
-        return -1;
-    }
-    const CarryWs w = carry_ws(d, workspace);
-    out->carry = nullptr; out->vals = w.cand_vals; out->cols = w.cand_cols; out->cnt = w.cand_cnt; out->C = w.C;
-    return 0;
-}
-}  // namespace mtc
-
-static int select_carry_impl(const mtc_desc* d, const void* acts, uint32_t k_total, void* workspace, size_t workspace_bytes,
-                             uint32_t* carry, mtc_select_state* st, int32_t* row_ptr, int32_t* col_idx, void* vals,
-                             void* stream, bool collected) {
+extern "C" int mtc_select_global_topk_carry(const mtc_desc* d, const void* acts, uint32_t k_total, void* workspace,
+                                            size_t workspace_bytes, uint32_t* carry, mtc_select_state* st,
+                                            int32_t* row_ptr, int32_t* col_idx, void* vals, void* stream) {
     if (check_desc(d, "mtc_select_global_topk_carry")) return -1;
     MTC_REQUIRE(acts && workspace && carry && st && row_ptr && col_idx && vals, "mtc_select_global_topk_carry: null pointer");
     MTC_REQUIRE(workspace_bytes >= mtc_select_carry_workspace_bytes(d),
                 "mtc_select_global_topk_carry: workspace too small (%zu < %zu)", workspace_bytes,
                 mtc_select_carry_workspace_bytes(d));
     hipStream_t s = as_stream(stream);
-    const CarryWs w = carry_ws(d, workspace);
-    const int C = w.C;
-    uint32_t *hist = w.hist, *row_gt = w.row_gt, *row_eq = w.row_eq, *tie_take = w.tie_take, *row_above = w.row_above,
-             *row_sub = w.row_sub, *cand_cnt = w.cand_cnt;
-    char* cand_vals = w.cand_vals;
-    int32_t* cand_cols = w.cand_cols;
+    const int C = carry_cols(d);
+    const size_t es = d->dtype == MTC_BF16 ? 2 : 4;
+    char* ws = reinterpret_cast<char*>(workspace);
+    uint32_t* hist = reinterpret_cast<uint32_t*>(ws);
+    const size_t bpad = (size_t)((d->B + 63) & ~63);
+    uint32_t* row_gt = hist + 3 * HIST_BINS;
+    uint32_t* row_eq = row_gt + bpad;
+    uint32_t* tie_take = row_eq + bpad;
+    uint32_t* row_above = tie_take + bpad;
+    uint32_t* row_sub = row_above + bpad;
+    char* cand_vals = ws + ((mtc_select_workspace_bytes(d) + 255) & ~(size_t)255);
+    int32_t* cand_cols = reinterpret_cast<int32_t*>(cand_vals + (((size_t)d->B * C * es + 255) & ~(size_t)255));
+    uint32_t* cand_cnt = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(cand_cols) +
+                                                     (((size_t)d->B * C * sizeof(int32_t) + 255) & ~(size_t)255));
     const uint32_t* flag = carry + 1;
     int rc;
     // one pass over acts with the carried bound, then the verdict (flag) for the launches below
-    if (collected)      // the encoder's epilogue already dropped them into the workspace: put each row in column order
-        DISPATCH_DT(d->dtype, select_sort_candidates_kernel, dim3((d->B + 3) / 4), dim3(256), 0, s, d->B, C, carry,
-                    (void*)cand_vals, cand_cols, cand_cnt);
-    else
-        DISPATCH_DT(d->dtype, select_candidates_kernel, dim3((d->B + 3) / 4), dim3(256), 0, s, acts, d->B, d->D, C, carry,
-                    (void*)cand_vals, cand_cols, cand_cnt);
+    DISPATCH_DT(d->dtype, select_candidates_kernel, dim3((d->B + 3) / 4), dim3(256), 0, s, acts, d->B, d->D, C, carry,
+                (void*)cand_vals, cand_cols, cand_cnt);
     hipLaunchKernelGGL(select_carry_decide_kernel, dim3(1), dim3(1024), 0, s, carry, cand_cnt, d->B, C, k_total, st, hist);
     if ((rc = check_launch("mtc_select_global_topk_carry"))) return rc;
     // streaming passes come in pairs (compact matrix if flag == 1, acts if flag == 0); the scans between
@@ -1027,18 +957,6 @@ static int select_carry_impl(const mtc_desc* d, const void* acts, uint32_t k_tot
     if ((rc = offsets_impl(d, row_gt, row_eq, nullptr, st, row_ptr, tie_take, carry, stream))) return rc;
     if ((rc = fill_impl(d, C, cand_vals, st, nullptr, row_ptr, tie_take, col_idx, vals, cand_cols, flag, 1, stream))) return rc;
     return fill_impl(d, d->D, acts, st, nullptr, row_ptr, tie_take, col_idx, vals, nullptr, flag, 0, stream);
-}
-
-extern "C" int mtc_select_global_topk_carry(const mtc_desc* d, const void* acts, uint32_t k_total, void* workspace,
-                                            size_t workspace_bytes, uint32_t* carry, mtc_select_state* st,
-                                            int32_t* row_ptr, int32_t* col_idx, void* vals, void* stream) {
-    return select_carry_impl(d, acts, k_total, workspace, workspace_bytes, carry, st, row_ptr, col_idx, vals, stream, false);
-}
-
-extern "C" int mtc_select_global_topk_collected(const mtc_desc* d, const void* acts, uint32_t k_total, void* workspace,
-                                                size_t workspace_bytes, uint32_t* carry, mtc_select_state* st,
-                                                int32_t* row_ptr, int32_t* col_idx, void* vals, void* stream) {
-    return select_carry_impl(d, acts, k_total, workspace, workspace_bytes, carry, st, row_ptr, col_idx, vals, stream, true);
 }
 
 extern "C" int mtc_select_offsets_sharded(const mtc_desc* d, const uint32_t* row_gt, const uint32_t* all_eq, int32_t eq_stride,

@@ -107,20 +107,10 @@ class HotPath:
         return xn, mean, std
 
     # ------------------------------------------------------------------ a3 dense part
-    def select_carry_workspace(self, d, device) -> torch.Tensor:
-        return torch.empty(self.lib.mtc_select_carry_workspace_bytes(C.byref(d)), dtype=torch.uint8, device=device)
-
-    def encode(self, d, x_norm, W_encT, b_enc, collect_ws: Optional[torch.Tensor] = None):
-        """collect_ws (a select_carry_workspace): the epilogue also drops every activation >= the carried bound of the
-        TopK threshold into that workspace, for select_topk(..., collected_ws=...) to finish without re-reading acts."""
+    def encode(self, d, x_norm, W_encT, b_enc):
         _need(W_encT, "W_encT", self.dtype, (self.D, self.A_s))
         _need(b_enc, "b_enc", self.dtype, (self.D,))
         acts = torch.empty(d.B, self.D, dtype=self.dtype, device=x_norm.device)
-        if collect_ws is not None:
-            check(self.lib.mtc_encode_fwd_collect(C.byref(d), _p(x_norm), _p(W_encT), _p(b_enc), _p(acts),
-                                                  _p(self.carry_state(x_norm.device)), _p(collect_ws), collect_ws.numel(),
-                                                  _stream()), "mtc_encode_fwd_collect")
-            return acts
         check(self.lib.mtc_encode_fwd(C.byref(d), _p(x_norm), _p(W_encT), _p(b_enc), _p(acts), _stream()), "mtc_encode_fwd")
         return acts
 
@@ -141,22 +131,15 @@ class HotPath:
             self._carry[key] = torch.zeros(8, dtype=torch.int32, device=device)
         return self._carry[key]
 
-    def select_topk(self, d, acts, k_total: int, carry: bool = False, collected_ws: Optional[torch.Tensor] = None) -> Selection:
+    def select_topk(self, d, acts, k_total: int, carry: bool = False) -> Selection:
         """Global batch-TopK.  carry=True (training loop): use / refresh the lower bound of tau carried from
-        the previous call on this device (identical result, one pass over acts instead of three).
-        collected_ws: the workspace the encoder's epilogue already filled (encode(..., collect_ws=...))."""
+        the previous call on this device (identical result, one pass over acts instead of three)."""
         dev = acts.device
         st = torch.empty(16, dtype=torch.int32, device=dev)
         row_ptr = torch.empty(d.B + 1, dtype=torch.int32, device=dev)
         cap = max(int(k_total), 1)
         col_idx = torch.empty(cap, dtype=torch.int32, device=dev)
         vals = torch.empty(cap, dtype=self.dtype, device=dev)
-        if collected_ws is not None:
-            check(self.lib.mtc_select_global_topk_collected(C.byref(d), _p(acts), int(k_total), _p(collected_ws),
-                                                            collected_ws.numel(), _p(self.carry_state(dev)), _p(st),
-                                                            _p(row_ptr), _p(col_idx), _p(vals), _stream()),
-                  "mtc_select_global_topk_collected")
-            return Selection(st, row_ptr, col_idx, vals)
         if carry:
             ws_bytes = self.lib.mtc_select_carry_workspace_bytes(C.byref(d))
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)

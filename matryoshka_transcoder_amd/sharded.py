@@ -134,7 +134,6 @@ class _Comm:
 
 class ShardedMatryoshkaTranscoder(MatryoshkaTranscoder):
     _overlap_ok = False        # one stream: the step is a chain of kernels and collectives
-    _collect_ok = False        # the sharded select exchanges histograms; its passes read the local activations
 
     def __init__(self, cfg: dict, group=None):
         if not dist.is_initialized():

@@ -197,7 +197,6 @@ class MatryoshkaTranscoder(nn.Module):
         self._dead_check_in = max(int(math.ceil(n_dead_at - mx)) - 1, 0)
         return False
 
-    _collect_ok = True                 # single-GPU model: select candidates come out of the encoder's epilogue
     _OVERLAP_MIN_ELEMS = 1 << 25       # below this a step is launch-bound and a second stream only adds host work
 
     def _join_csc(self):
@@ -231,16 +230,8 @@ class MatryoshkaTranscoder(nn.Module):
         else:
             xn, mean, std = x_source, None, None
             self.x_mean = self.x_std = None
-        if self.training and self._collect_ok:
-            # training step: the encoder's epilogue hands the select its candidates (activations >= the bound carried
-            # from the previous step), so the [B, D] activations are not read again on the common path
-            ws = hp.select_carry_workspace(d, x_source.device)
-            acts = hp.encode(d, xn, self._w_encT(W_enc), b_enc.contiguous(), collect_ws=ws)
-            sel = hp.select_topk(d, acts, int(cfg["top_k"]) * B, collected_ws=ws)
-            hp.threshold_ema(d, sel, self.threshold)
-        else:
-            acts = hp.encode(d, xn, self._w_encT(W_enc), b_enc.contiguous())
-            sel = self._select(hp, d, acts, self.training)
+        acts = hp.encode(d, xn, self._w_encT(W_enc), b_enc.contiguous())
+        sel = self._select(hp, d, acts, self.training)
         if self._cnt.device != x_source.device or self._cnt.dtype != torch.float32:
             self._cnt = self._cnt.to(device=x_source.device, dtype=torch.float32)
         # counters BEFORE aux (sae.py:233,242).  In the fused training step the CSC build (a chain of small latency-bound
