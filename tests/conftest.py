@@ -16,6 +16,11 @@ SMALL_CASES = ["fp32_plain", "fp32_unit", "fp32_cross", "fp32_aux", "fp32_aux_un
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a fresh checkout has no libmtc.so (built artefacts are not tracked): build it once, in-tree, if a compiler is here
+    lib = os.path.join(ROOT, "matryoshka_transcoder_amd", "libmtc.so")
+    if not os.path.exists(lib) and os.path.exists("/opt/rocm/bin/hipcc"):
+        import subprocess
+        subprocess.run(["make", "-j8"], cwd=ROOT, check=False, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 
 
 def load_golden(name):
