@@ -85,8 +85,8 @@ class FusedAdam(torch.optim.Optimizer):
         finally:
             tc._defer_dvals = False
         tc._last_res = res
-        out = tc._output_dict(res, x_target)
         hp = tc.hot_path()
+        two_streams = getattr(tc, "_two_streams", False)     # this step issued work on the side stream (see _run_forward)
         extra = None
         if res.aux is not None and res.aux.get("dense") and res.d_vals is None:
             # dense aux branch: its gradient rows over the dead set (three GEMMs) ride into the fused kernels
@@ -96,11 +96,13 @@ class FusedAdam(torch.optim.Optimizer):
             extra = (row_map,) + tuple(t.contiguous() for t in hp.aux_extra_rows(a, res.x_norm))
         elif res.aux is not None:
             tc._join_csc()
+            if two_streams:
+                torch.cuda.current_stream().wait_stream(tc._side_stream)
             dW_dec, dW_encT, db_enc, db_dec = tc._run_backward(res, None)
             tc.W_dec.grad, tc.W_enc.grad, tc.b_enc.grad, tc.b_dec.grad = dW_dec, dW_encT.t(), db_enc, db_dec
             self.step(project=True)
             self.zero_grad()
-            return out
+            return tc._output_dict(res, x_target)
         group = self.param_groups[0]
         b1, b2 = group["betas"]
         hy = {}
@@ -118,9 +120,8 @@ class FusedAdam(torch.optim.Optimizer):
             db_dec = hp.colsum(res.desc, res.g)
             hp.adam_flat(tc.b_dec.data, db_dec, sbd["exp_avg"], sbd["exp_avg_sq"], hy["b_dec"])
 
-        overlapped = tc._csc_event is not None          # this step runs two streams (see _run_forward)
         e_b = None
-        if overlapped:
+        if two_streams:
             # the b_dec update only needs g: it runs on the side stream underneath the two gradient kernels
             main, side = torch.cuda.current_stream(), tc._side_stream
             e_g = torch.cuda.Event()
@@ -136,10 +137,10 @@ class FusedAdam(torch.optim.Optimizer):
                                (sb["exp_avg"], sb["exp_avg_sq"]), hy["W_dec"], hy["W_enc"], hy["b_enc"],
                                l1_term=float(tc.config["l1_coeff"]) / (res.desc.B * tc.total_dict_size), extra=extra)
         if e_b is not None:
-            torch.cuda.current_stream().wait_event(e_b)     # every later reader of b_dec / g is ordered behind the side stream
+            torch.cuda.current_stream().wait_event(e_b)     # every later reader of b_dec / g / the scalars is ordered behind the side stream
         else:
             update_b_dec()
-        return out
+        return tc._output_dict(res, x_target)
 
     @torch.no_grad()
     def step(self, closure=None, project: bool = False):

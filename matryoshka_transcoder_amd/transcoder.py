@@ -238,7 +238,8 @@ class MatryoshkaTranscoder(nn.Module):
         # kernels nobody needs before the gradient kernels) runs on a side stream underneath the decode launch.
         side = getattr(self, "_side_stream", None)
         self._csc_event = None
-        if side is not None and getattr(self, "_defer_dvals", False) and B * hp.D >= self._OVERLAP_MIN_ELEMS:
+        self._two_streams = side is not None and getattr(self, "_defer_dvals", False) and B * hp.D >= self._OVERLAP_MIN_ELEMS
+        if self._two_streams:
             main = torch.cuda.current_stream()
             e_sel = torch.cuda.Event()
             e_sel.record(main)
@@ -276,8 +277,19 @@ class MatryoshkaTranscoder(nn.Module):
             # gradient kernel when the aux branch is in its dense form, otherwise it is needed here
             if need_grad and not (defer and (aux is None or aux.get("dense"))):
                 d_vals = hp.decode_bwd_vals(d, sel, W_dec, g, l1_term)
-        scalars = hp.reduce_scalars(d, row_stats, sel, self.total_dict_size, float(cfg["l1_coeff"]),
-                                    float(cfg["aux_penalty"]), aux_rows=aux_rows)
+        if getattr(self, "_two_streams", False):
+            # fused training step on two streams: the loss / FVU reduction (one small workgroup) leaves the critical
+            # path too; FusedAdam.train_step joins the side stream before anything reads the scalars
+            main, side = torch.cuda.current_stream(), self._side_stream
+            e_rows = torch.cuda.Event()
+            e_rows.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(e_rows)
+                scalars = hp.reduce_scalars(d, row_stats, sel, self.total_dict_size, float(cfg["l1_coeff"]),
+                                            float(cfg["aux_penalty"]), aux_rows=aux_rows)
+        else:
+            scalars = hp.reduce_scalars(d, row_stats, sel, self.total_dict_size, float(cfg["l1_coeff"]),
+                                        float(cfg["aux_penalty"]), aux_rows=aux_rows)
         return x_hat, g, d_vals, row_stats, scalars, aux
 
     def _run_aux(self, hp, d, acts, sel, W_dec, x_target, x_hat, g, need_grad, l1_term):
