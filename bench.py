@@ -152,8 +152,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    torch.cuda.set_device(local_rank)
-    device = f"cuda:{local_rank}"
+    # one rank per GPU; with fewer GPUs than ranks (rehearsal on a one-GPU box) the ranks share the cards
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    device = f"cuda:{dev_index}"
     if world > 1 or args.sharded:
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:
@@ -164,7 +166,12 @@ def main():
         saved_fd = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", device_id=torch.device(device))
+            if int(os.environ.get("LOCAL_WORLD_SIZE", "1")) > max(torch.cuda.device_count(), 1):
+                # rehearsal only: RCCL refuses two ranks on one GPU ("Duplicate GPU detected"), so ranks that share a
+                # card exchange through gloo (device tensors staged through the host, sharded._Comm)
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=torch.device(device))
             dist.barrier()
             torch.cuda.synchronize()
         finally:
