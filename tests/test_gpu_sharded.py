@@ -51,11 +51,14 @@ def _train(model, opt, batches, fused=False):
     return log
 
 
-def _worker(rank, world, port, dt_name, unit, fused, aux, ret):
+def _worker(rank, world, port, dt_name, unit, fused, aux, ret, backend="gloo"):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         torch.cuda.set_device(0)
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda:0"))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
         from matryoshka_transcoder_amd.sharded import ShardedFusedAdam, ShardedMatryoshkaTranscoder
         dt = getattr(torch, dt_name)
         cfg = _cfg(dt, unit, aux)
@@ -139,3 +142,36 @@ def test_sharded_matches_single_gpu(dt_name, unit, fused, aux, gpu_lib):
             ulp = (v.float().abs() * 2 ** -7).clamp_min(2 ** -14)
             n_off = int(((got.float() - v.float()).abs() > ulp).sum())
             assert n_off <= 0.03 * v.numel() + 8, (k, n_off, v.numel())
+
+
+@pytest.mark.parametrize("dt_name,unit,aux", [("float32", False, False), ("bfloat16", True, "gemm")])
+def test_sharded_over_rccl_world1_matches_single_gpu(dt_name, unit, aux, gpu_lib):
+    """The transport bench.py uses at N > 1: RCCL through torch.distributed on device tensors (sharded._Comm without
+    host staging: reduce_scatter_tensor / all_gather_into_tensor / all_reduce).  RCCL refuses two ranks on one GPU, so
+    on the one-GPU test box the group has ONE rank; the exchanges are then identities and the fused step must
+    reproduce the single-GPU classes' losses."""
+    from matryoshka_transcoder_amd.training import FusedAdam
+    from matryoshka_transcoder_amd.transcoder import MatryoshkaTranscoder
+    dt = getattr(torch, dt_name)
+    cfg = _cfg(dt, unit, aux)
+    ref = MatryoshkaTranscoder(cfg)
+    n = 6 if aux else 3
+    ref_log = _train(ref, FusedAdam(ref, lr=cfg["lr"], betas=(cfg["beta1"], cfg["beta2"])), _batches(dt, n=n), fused=True)
+    ref_sd = {k: v.cpu() for k, v in ref.state_dict().items()}
+    torch.cuda.synchronize()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    p = ctx.Process(target=_worker, args=(0, 1, _free_port(), dt_name, unit, True, aux, ret, "nccl"))
+    p.start()
+    p.join(170)
+    assert ret.get(0) == "ok", ret.get(0)
+    f32 = dt == torch.float32
+    rtol = 1e-5 if f32 else 2e-2
+    for a, b in zip(ret["log"], ref_log):
+        for k in b:
+            assert abs(a[k] - b[k]) <= rtol * abs(b[k]) + 1e-7, (k, a[k], b[k])
+    for k, v in ref_sd.items():
+        got = ret["sd"][k]
+        assert got.shape == v.shape
+        if f32:
+            assert torch.allclose(got, v, rtol=0, atol=1e-2 * cfg["lr"] + 1e-7), k
