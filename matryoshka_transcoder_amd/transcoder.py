@@ -92,6 +92,14 @@ class MatryoshkaTranscoder(nn.Module):
         self.to(cfg["dtype"]).to(cfg["device"])
 
     # ------------------------------------------------------------------ plumbing
+    def __setattr__(self, name, value):
+        # per-step bookkeeping (`_last_res`, `_csc_event`, `x_mean`, ...) is plain state, never a Parameter / buffer /
+        # sub-module: nn.Module.__setattr__ spends ~6 us per assignment checking for those, ~8 times per step
+        if (name[0] == "_" or name in ("x_mean", "x_std")) and not isinstance(value, (nn.Parameter, nn.Module)):
+            object.__setattr__(self, name, value)
+        else:
+            super().__setattr__(name, value)
+
     @property
     def num_batches_not_active(self) -> torch.Tensor:
         """Dead-feature counters (sae.py:134).  Handing the tensor out (or replacing it) voids the
