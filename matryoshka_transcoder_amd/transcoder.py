@@ -347,17 +347,25 @@ class MatryoshkaTranscoder(nn.Module):
     def _output_dict(self, res, x_target, loss=None):
         """The reference's 11 keys with its dtypes (sae.py:257-269), from the device-resident scalars."""
         s, dt = res.scalars, self.dtype
+        # the kernel already rounded l2 / l1 / l1_norm / loss to the model dtype (mtc_reduce_scalars), so ONE conversion of
+        # the 16-float vector yields all of them exactly (a no-op for fp32 models); the entries are views of it
+        sd = s.to(dt)
         if loss is None:
-            loss = s[5].clone() if res.aux is not None else s[5].to(dt)
-        # aux inactive: a 0-dim zero in the target dtype; active: fp32 (sae.py:342-347)
-        aux_loss = s[4] if res.aux is not None else torch.zeros((), dtype=x_target.dtype, device=x_target.device)
+            loss = s[5].clone() if res.aux is not None else sd[5]
+        # aux inactive: a 0-dim zero in the target dtype (slot 4 holds 0 then); active: fp32 (sae.py:342-347)
+        if res.aux is not None:
+            aux_loss = s[4]
+        elif x_target.dtype == dt:
+            aux_loss = sd[4]
+        else:
+            aux_loss = torch.zeros((), dtype=x_target.dtype, device=x_target.device)
         return {
             "transcoder_out": res.x_hat,
             "loss": loss,
-            "l2_loss": s[0].to(dt),
-            "l1_loss": s[1].to(dt),
+            "l2_loss": sd[0],
+            "l1_loss": sd[1],
             "l0_norm": s[2],
-            "l1_norm": s[3].to(dt),
+            "l1_norm": sd[3],
             "aux_loss": aux_loss,
             "fvu": s[6],
             "fvu_min": s[7],
