@@ -43,12 +43,26 @@ __global__ void select_init_kernel(mtc_select_state* st, uint32_t k_total) {
 }
 
 template <int DT>
-__global__ __launch_bounds__(256) void select_hist_kernel(const void* __restrict__ acts, size_t n_chunks, int level,
+__global__ __launch_bounds__(256) void select_hist_kernel(const void* __restrict__ acts_in, size_t n_chunks, int level,
                                                           const mtc_select_state* __restrict__ st,
                                                           uint32_t* __restrict__ hist,
-                                                          const uint32_t* __restrict__ pred, uint32_t want) {
+                                                          const uint32_t* __restrict__ pred, uint32_t want,
+                                                          const void* __restrict__ alt_acts, size_t alt_chunks,
+                                                          uint32_t grid_main, uint32_t grid_alt) {
     __shared__ uint32_t lh[HIST_BINS];
-    if (pred && *pred != want) return;                 // uniform: the other of the compact / full paths runs
+    // pred == null: plain pass.  pred, no alt: runs only if *pred == want.  pred + alt (ONE launch for the compact / full
+    // pair of the carried-bound select): *pred == want streams `acts_in`, otherwise `alt_acts`; the grid is sized for the
+    // larger of the two and the surplus workgroups leave at once
+    const void* acts = acts_in;
+    uint32_t nblk = gridDim.x;
+    if (pred) {
+        const bool m = *pred == want;                  // uniform
+        if (alt_acts) {
+            if (!m) { acts = alt_acts; n_chunks = alt_chunks; }
+            nblk = m ? grid_main : grid_alt;
+            if (blockIdx.x >= nblk) return;
+        } else if (!m) return;
+    }
     for (int i = threadIdx.x; i < HIST_BINS; i += 256) lh[i] = 0;
     __syncthreads();
     const uint32_t all_pos = st->all_pos;
@@ -57,7 +71,7 @@ __global__ __launch_bounds__(256) void select_hist_kernel(const void* __restrict
     const uint32_t fm = level_mask(level), pm = level_prefix_mask(level);
     if (!(all_pos && level > 0)) {
         // 4 independent 16-byte loads per lane per iteration (memory-level parallelism)
-        const size_t stride = (size_t)gridDim.x * 256;
+        const size_t stride = (size_t)nblk * 256;
         for (size_t c0 = (size_t)blockIdx.x * 256 + threadIdx.x; c0 < n_chunks; c0 += 4 * stride) {
             Raw<DT> r[4];
 #pragma unroll
@@ -130,15 +144,23 @@ __global__ __launch_bounds__(1024) void select_scan_kernel(const uint32_t* __res
 
 // wave per row: counts of (> tau) and (== tau); threshold mode: (> thr) only
 template <int DT>
-__global__ __launch_bounds__(256) void select_count_kernel(const void* __restrict__ acts, int B, int D,
+__global__ __launch_bounds__(256) void select_count_kernel(const void* __restrict__ acts_in, int B, int D,
                                                            mtc_select_state* __restrict__ st,
                                                            const void* __restrict__ threshold,
                                                            uint32_t* __restrict__ row_gt, uint32_t* __restrict__ row_eq,
-                                                           const uint32_t* __restrict__ pred, uint32_t want) {
+                                                           const uint32_t* __restrict__ pred, uint32_t want,
+                                                           const void* __restrict__ alt_acts, int alt_D) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= B) return;
-    if (pred && *pred != want) return;
+    // pred + alt: ONE launch serves the compact / full pair (*pred == want streams `acts_in`, otherwise the alt matrix)
+    bool use_alt = false;
+    if (pred && *pred != want) {                        // uniform
+        if (!alt_acts) return;
+        use_alt = true;
+    }
+    const void* __restrict__ acts = use_alt ? alt_acts : acts_in;
+    if (use_alt) { D = alt_D; }
     float tau; bool ties = false, nz = false;
     if (threshold) {
         tau = DType<DT>::ld(reinterpret_cast<const typename DType<DT>::T*>(threshold));
@@ -171,22 +193,32 @@ __global__ __launch_bounds__(256) void select_count_kernel(const void* __restric
     for (int o = 32; o > 0; o >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, o, 64));
     if (lane == 0) {
         row_gt[row] = gt; row_eq[row] = eq;
-        note_min_selected(st, mn);
+        // with a tau the smallest selected value IS tau (the k-th largest entry is selected; the offsets kernel notes it):
+        // 4096 waves arriving together would all pass the pruning load and queue up on one address (~20 us)
+        if (!ties) note_min_selected(st, mn);
     }
 }
 
 // bf16 fast path: after level 0 only 3 key bits remain, so one pass per row can count, for every
 // row, the entries above the level-0 bin and the 8 sub-bin populations inside it; tau, the tie
 // quota and the per-row (> tau, == tau) counts then follow without another pass over acts.
-__global__ __launch_bounds__(256) void select_rowsub_bf16_kernel(const void* __restrict__ acts, int B, int D,
+__global__ __launch_bounds__(256) void select_rowsub_bf16_kernel(const void* __restrict__ acts_in, int B, int D,
                                                                  mtc_select_state* __restrict__ st,
                                                                  uint32_t* __restrict__ row_above,
                                                                  uint32_t* __restrict__ row_sub /* [B][8] */,
-                                                                 const uint32_t* __restrict__ pred, uint32_t want) {
+                                                                 const uint32_t* __restrict__ pred, uint32_t want,
+                                                                 const void* __restrict__ alt_acts, int alt_D) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= B) return;
-    if (pred && *pred != want) return;
+    // pred + alt: ONE launch serves the compact / full pair (*pred == want streams `acts_in`, otherwise the alt matrix)
+    bool use_alt = false;
+    if (pred && *pred != want) {                        // uniform
+        if (!alt_acts) return;
+        use_alt = true;
+    }
+    const void* __restrict__ acts = use_alt ? alt_acts : acts_in;
+    if (use_alt) { D = alt_D; }
     const bool all_pos = st->all_pos != 0;
     const uint32_t bin = st->key_prefix >> 19;            // level-0 bin of tau
     const size_t base = (size_t)row * D;
@@ -227,7 +259,7 @@ __global__ __launch_bounds__(256) void select_rowsub_bf16_kernel(const void* __r
         row_above[row] = above;
 #pragma unroll
         for (int q = 0; q < 8; ++q) row_sub[(size_t)row * 8 + q] = sub[q];
-        note_min_selected(st, mn);
+        if (all_pos) note_min_selected(st, mn);         // otherwise min selected = tau, noted by the offsets kernel (see select_count_kernel)
     }
 }
 
@@ -354,19 +386,28 @@ __global__ __launch_bounds__(1024) void select_offsets_kernel(int B, const uint3
 
 // wave per row: ordered compaction of the selected entries
 template <int DT>
-__global__ __launch_bounds__(256) void select_fill_kernel(const void* __restrict__ acts, int B, int D,
+__global__ __launch_bounds__(256) void select_fill_kernel(const void* __restrict__ acts_in, int B, int D,
                                                           const mtc_select_state* __restrict__ st,
                                                           const void* __restrict__ threshold,
                                                           const int32_t* __restrict__ row_ptr,
                                                           const uint32_t* __restrict__ tie_take,
                                                           int32_t* __restrict__ col_idx, void* __restrict__ vals,
-                                                          const int32_t* __restrict__ col_map /* [B][D] or null */,
-                                                          const uint32_t* __restrict__ pred, uint32_t want) {
+                                                          const int32_t* __restrict__ col_map_in /* [B][D] or null */,
+                                                          const uint32_t* __restrict__ pred, uint32_t want,
+                                                          const void* __restrict__ alt_acts, int alt_D) {
     typedef typename DType<DT>::T T;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= B) return;
-    if (pred && *pred != want) return;
+    const int32_t* col_map = col_map_in;
+    // pred + alt: ONE launch serves the compact / full pair (*pred == want streams `acts_in`, otherwise the alt matrix)
+    bool use_alt = false;
+    if (pred && *pred != want) {                        // uniform
+        if (!alt_acts) return;
+        use_alt = true;
+    }
+    const void* __restrict__ acts = use_alt ? alt_acts : acts_in;
+    if (use_alt) { D = alt_D; col_map = nullptr; }     // the alt (full) matrix is in natural column order
     float tau; uint32_t quota = 0; bool nz = false;
     if (threshold) {
         tau = DType<DT>::ld(reinterpret_cast<const T*>(threshold));
@@ -755,13 +796,17 @@ extern "C" int mtc_select_init(mtc_select_state* st, uint32_t k_total, void* str
 }
 
 // `cols` = row length of the matrix the pass streams (D, or C for the compact candidate matrix)
+// every workgroup zeroes and flushes a 4096-bin LDS histogram: give each at least 16 chunks per thread
+static uint32_t hist_grid(size_t n_chunks) {
+    return (uint32_t)std::max<size_t>(1, std::min<size_t>((n_chunks + 256 * 16 - 1) / (256 * 16), 2048));
+}
+// alt_acts != null (needs pred): one launch for both matrices, see the kernel
 static int hist_impl(const mtc_desc* d, int cols, const void* acts, int level, const mtc_select_state* st, uint32_t* hist,
-                     const uint32_t* pred, uint32_t want, void* stream) {
-    const size_t n_chunks = (size_t)d->B * cols / 8;
-    // every workgroup zeroes and flushes a 4096-bin LDS histogram: give each at least 16 chunks per thread
-    const int grid = (int)std::max<size_t>(1, std::min<size_t>((n_chunks + 256 * 16 - 1) / (256 * 16), 2048));
-    DISPATCH_DT(d->dtype, select_hist_kernel, dim3(grid), dim3(256), 0, as_stream(stream), acts, n_chunks, level, st, hist,
-                pred, want);
+                     const uint32_t* pred, uint32_t want, void* stream, const void* alt_acts = nullptr, int alt_cols = 0) {
+    const size_t n_chunks = (size_t)d->B * cols / 8, alt_chunks = (size_t)d->B * alt_cols / 8;
+    const uint32_t g_main = hist_grid(n_chunks), g_alt = alt_acts ? hist_grid(alt_chunks) : 0;
+    DISPATCH_DT(d->dtype, select_hist_kernel, dim3(std::max(g_main, g_alt)), dim3(256), 0, as_stream(stream), acts, n_chunks,
+                level, st, hist, pred, want, alt_acts, alt_chunks, g_main, g_alt);
     return check_launch("mtc_select_hist");
 }
 extern "C" int mtc_select_hist(const mtc_desc* d, const void* acts, int level, const mtc_select_state* st,
@@ -781,9 +826,10 @@ extern "C" int mtc_select_scan(const mtc_desc* d, int level, const uint32_t* his
 }
 
 static int count_impl(const mtc_desc* d, int cols, const void* acts, const mtc_select_state* st, const void* threshold,
-                      uint32_t* row_gt, uint32_t* row_eq, const uint32_t* pred, uint32_t want, void* stream) {
+                      uint32_t* row_gt, uint32_t* row_eq, const uint32_t* pred, uint32_t want, void* stream,
+                      const void* alt_acts = nullptr, int alt_cols = 0) {
     DISPATCH_DT(d->dtype, select_count_kernel, dim3((d->B + 3) / 4), dim3(256), 0, as_stream(stream), acts, d->B, cols,
-                const_cast<mtc_select_state*>(st), threshold, row_gt, row_eq, pred, want);
+                const_cast<mtc_select_state*>(st), threshold, row_gt, row_eq, pred, want, alt_acts, alt_cols);
     return check_launch("mtc_select_count");
 }
 extern "C" int mtc_select_count(const mtc_desc* d, const void* acts, const mtc_select_state* st, const void* threshold,
@@ -809,9 +855,9 @@ extern "C" int mtc_select_offsets(const mtc_desc* d, const uint32_t* row_gt, con
 
 static int fill_impl(const mtc_desc* d, int cols, const void* acts, const mtc_select_state* st, const void* threshold,
                      const int32_t* row_ptr, const uint32_t* tie_take, int32_t* col_idx, void* vals, const int32_t* col_map,
-                     const uint32_t* pred, uint32_t want, void* stream) {
+                     const uint32_t* pred, uint32_t want, void* stream, const void* alt_acts = nullptr, int alt_cols = 0) {
     DISPATCH_DT(d->dtype, select_fill_kernel, dim3((d->B + 3) / 4), dim3(256), 0, as_stream(stream), acts, d->B, cols,
-                st, threshold, row_ptr, tie_take, col_idx, vals, col_map, pred, want);
+                st, threshold, row_ptr, tie_take, col_idx, vals, col_map, pred, want, alt_acts, alt_cols);
     return check_launch("mtc_select_fill");
 }
 extern "C" int mtc_select_fill(const mtc_desc* d, const void* acts, const mtc_select_state* st, const void* threshold,
@@ -823,9 +869,10 @@ extern "C" int mtc_select_fill(const mtc_desc* d, const void* acts, const mtc_se
 }
 
 static int rowsub_impl(const mtc_desc* d, int cols, const void* acts, mtc_select_state* st, uint32_t* row_above,
-                       uint32_t* row_sub, const uint32_t* pred, uint32_t want, void* stream) {
+                       uint32_t* row_sub, const uint32_t* pred, uint32_t want, void* stream, const void* alt_acts = nullptr,
+                       int alt_cols = 0) {
     hipLaunchKernelGGL(select_rowsub_bf16_kernel, dim3((d->B + 3) / 4), dim3(256), 0, as_stream(stream), acts, d->B, cols, st,
-                       row_above, row_sub, pred, want);
+                       row_above, row_sub, pred, want, alt_acts, alt_cols);
     return check_launch("mtc_select_rowsub");
 }
 extern "C" int mtc_select_rowsub(const mtc_desc* d, const void* acts, mtc_select_state* st, uint32_t* row_above,
@@ -935,28 +982,23 @@ extern "C" int mtc_select_global_topk_carry(const mtc_desc* d, const void* acts,
                 (void*)cand_vals, cand_cols, cand_cnt);
     hipLaunchKernelGGL(select_carry_decide_kernel, dim3(1), dim3(1024), 0, s, carry, cand_cnt, d->B, C, k_total, st, hist);
     if ((rc = check_launch("mtc_select_global_topk_carry"))) return rc;
-    // streaming passes come in pairs (compact matrix if flag == 1, acts if flag == 0); the scans between
-    // them work on the shared histogram / per-row arrays whichever pass filled them
+    // each streaming pass is ONE launch that reads the compact matrix if flag == 1 and acts if flag == 0 (grid sized for
+    // the larger); the scans between them work on the shared histogram / per-row arrays whichever matrix filled them
     if (d->dtype == MTC_BF16) {
-        if ((rc = hist_impl(d, C, cand_vals, 0, st, hist, flag, 1, stream))) return rc;
-        if ((rc = hist_impl(d, d->D, acts, 0, st, hist, flag, 0, stream))) return rc;
+        if ((rc = hist_impl(d, C, cand_vals, 0, st, hist, flag, 1, stream, acts, d->D))) return rc;
         if ((rc = mtc_select_scan(d, 0, hist, st, stream))) return rc;
-        if ((rc = rowsub_impl(d, C, cand_vals, st, row_above, row_sub, flag, 1, stream))) return rc;
-        if ((rc = rowsub_impl(d, d->D, acts, st, row_above, row_sub, flag, 0, stream))) return rc;
+        if ((rc = rowsub_impl(d, C, cand_vals, st, row_above, row_sub, flag, 1, stream, acts, d->D))) return rc;
         if ((rc = mtc_select_finish_rows(d, st, row_above, row_sub, nullptr, row_gt, row_eq, stream))) return rc;
     } else {
         const int levels = mtc_select_levels(d);
         for (int l = 0; l < levels; ++l) {
-            if ((rc = hist_impl(d, C, cand_vals, l, st, hist + l * HIST_BINS, flag, 1, stream))) return rc;
-            if ((rc = hist_impl(d, d->D, acts, l, st, hist + l * HIST_BINS, flag, 0, stream))) return rc;
+            if ((rc = hist_impl(d, C, cand_vals, l, st, hist + l * HIST_BINS, flag, 1, stream, acts, d->D))) return rc;
             if ((rc = mtc_select_scan(d, l, hist + l * HIST_BINS, st, stream))) return rc;
         }
-        if ((rc = count_impl(d, C, cand_vals, st, nullptr, row_gt, row_eq, flag, 1, stream))) return rc;
-        if ((rc = count_impl(d, d->D, acts, st, nullptr, row_gt, row_eq, flag, 0, stream))) return rc;
+        if ((rc = count_impl(d, C, cand_vals, st, nullptr, row_gt, row_eq, flag, 1, stream, acts, d->D))) return rc;
     }
     if ((rc = offsets_impl(d, row_gt, row_eq, nullptr, st, row_ptr, tie_take, carry, stream))) return rc;
-    if ((rc = fill_impl(d, C, cand_vals, st, nullptr, row_ptr, tie_take, col_idx, vals, cand_cols, flag, 1, stream))) return rc;
-    return fill_impl(d, d->D, acts, st, nullptr, row_ptr, tie_take, col_idx, vals, nullptr, flag, 0, stream);
+    return fill_impl(d, C, cand_vals, st, nullptr, row_ptr, tie_take, col_idx, vals, cand_cols, flag, 1, stream, acts, d->D);
 }
 
 extern "C" int mtc_select_offsets_sharded(const mtc_desc* d, const uint32_t* row_gt, const uint32_t* all_eq, int32_t eq_stride,
