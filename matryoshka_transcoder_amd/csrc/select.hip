@@ -508,6 +508,20 @@ template <> __device__ __forceinline__ bool chunk_may_hold<MTC_F32>(const Raw<MT
     return mx >= guess;
 }
 
+// streaming read of the activations (read once here; keeps them from displacing lines other kernels reuse)
+template <int DT> __device__ __forceinline__ Raw<DT> load_raw_nt(const void* base, size_t elem_off);
+template <> __device__ __forceinline__ Raw<MTC_BF16> load_raw_nt<MTC_BF16>(const void* base, size_t elem_off) {
+    Raw<MTC_BF16> r;
+    r.v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(reinterpret_cast<const u16*>(base) + elem_off));
+    return r;
+}
+template <> __device__ __forceinline__ Raw<MTC_F32> load_raw_nt<MTC_F32>(const void* base, size_t elem_off) {
+    Raw<MTC_F32> r;
+    const f32x4* p = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + elem_off);
+    r.a = __builtin_nontemporal_load(p); r.b = __builtin_nontemporal_load(p + 1);
+    return r;
+}
+
 // Wave per row.  The row streams through registers (U chunks of 8 elements per lane in flight, the next block
 // requested before this one is looked at); a chunk that MAY hold a candidate (one packed-max test, ~0.5 % of the
 // elements are candidates) is appended, in column order, to a per-wave queue in LDS.  Whenever the queue holds more
@@ -582,7 +596,7 @@ __global__ __launch_bounds__(256) void select_candidates_kernel(const void* __re
     Raw<DT> nxt[U];
 #pragma unroll
     for (int u = 0; u < U; ++u)
-        if (64 * u + lane < nch) nxt[u] = load_raw<DT>(acts, base + (size_t)(64 * u + lane) * 8);
+        if (64 * u + lane < nch) nxt[u] = load_raw_nt<DT>(acts, base + (size_t)(64 * u + lane) * 8);
     for (int cb = 0; cb < nch; cb += 64 * U) {
         Raw<DT> cur[U];
 #pragma unroll
@@ -590,7 +604,7 @@ __global__ __launch_bounds__(256) void select_candidates_kernel(const void* __re
         const int nb = cb + 64 * U;                    // next block is requested before this one is scanned
 #pragma unroll
         for (int u = 0; u < U; ++u)
-            if (nb + 64 * u + lane < nch) nxt[u] = load_raw<DT>(acts, base + (size_t)(nb + 64 * u + lane) * 8);
+            if (nb + 64 * u + lane < nch) nxt[u] = load_raw_nt<DT>(acts, base + (size_t)(nb + 64 * u + lane) * 8);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (cb + 64 * u >= nch) break;                   // wave-uniform
