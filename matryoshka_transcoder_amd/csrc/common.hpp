@@ -92,6 +92,22 @@ template <> __device__ __forceinline__ void store8<MTC_F32>(void* base, size_t e
     p[0] = a; p[1] = b;
 }
 
+// streaming (non-temporal) form of store8: for rows nothing reads again soon (Adam moments)
+template <int DT> __device__ __forceinline__ void store8_nt(void* base, size_t elem_off, const float (&v)[8]);
+template <> __device__ __forceinline__ void store8_nt<MTC_BF16>(void* base, size_t elem_off, const float (&v)[8]) {
+    u32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = pack2_bf16(v[2 * i], v[2 * i + 1]);
+    __builtin_nontemporal_store(r, reinterpret_cast<u32x4*>(reinterpret_cast<u16*>(base) + elem_off));
+}
+template <> __device__ __forceinline__ void store8_nt<MTC_F32>(void* base, size_t elem_off, const float (&v)[8]) {
+    f32x4* p = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + elem_off);
+    f32x4 a, b;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[i] = v[i]; b[i] = v[4 + i]; }
+    __builtin_nontemporal_store(a, p); __builtin_nontemporal_store(b, p + 1);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

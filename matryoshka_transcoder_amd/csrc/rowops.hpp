@@ -31,6 +31,20 @@ template <> __device__ __forceinline__ Raw<MTC_F32> load_raw<MTC_F32>(const void
     r.a = p[0]; r.b = p[1];
     return r;
 }
+// streaming (non-temporal) read of data a kernel touches once: keeps it from displacing the lines other accesses reuse
+template <int DT> __device__ __forceinline__ Raw<DT> load_raw_nt(const void* base, size_t elem_off);
+template <> __device__ __forceinline__ Raw<MTC_BF16> load_raw_nt<MTC_BF16>(const void* base, size_t elem_off) {
+    Raw<MTC_BF16> r;
+    r.v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(reinterpret_cast<const u16*>(base) + elem_off));
+    return r;
+}
+template <> __device__ __forceinline__ Raw<MTC_F32> load_raw_nt<MTC_F32>(const void* base, size_t elem_off) {
+    Raw<MTC_F32> r;
+    const f32x4* p = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + elem_off);
+    r.a = __builtin_nontemporal_load(p); r.b = __builtin_nontemporal_load(p + 1);
+    return r;
+}
+
 __device__ __forceinline__ void unpack(const Raw<MTC_BF16>& r, float (&w)[8]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) { w[2 * i] = __uint_as_float(r.v[i] << 16); w[2 * i + 1] = __uint_as_float(r.v[i] & 0xffff0000u); }

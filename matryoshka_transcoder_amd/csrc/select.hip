@@ -508,20 +508,6 @@ template <> __device__ __forceinline__ bool chunk_may_hold<MTC_F32>(const Raw<MT
     return mx >= guess;
 }
 
-// streaming read of the activations (read once here; keeps them from displacing lines other kernels reuse)
-template <int DT> __device__ __forceinline__ Raw<DT> load_raw_nt(const void* base, size_t elem_off);
-template <> __device__ __forceinline__ Raw<MTC_BF16> load_raw_nt<MTC_BF16>(const void* base, size_t elem_off) {
-    Raw<MTC_BF16> r;
-    r.v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(reinterpret_cast<const u16*>(base) + elem_off));
-    return r;
-}
-template <> __device__ __forceinline__ Raw<MTC_F32> load_raw_nt<MTC_F32>(const void* base, size_t elem_off) {
-    Raw<MTC_F32> r;
-    const f32x4* p = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + elem_off);
-    r.a = __builtin_nontemporal_load(p); r.b = __builtin_nontemporal_load(p + 1);
-    return r;
-}
-
 // Wave per row.  The row streams through registers (U chunks of 8 elements per lane in flight, the next block
 // requested before this one is looked at); a chunk that MAY hold a candidate (one packed-max test, ~0.5 % of the
 // elements are candidates) is appended, in column order, to a per-wave queue in LDS.  Whenever the queue holds more
