@@ -269,7 +269,7 @@ def main():
         # HBM-side bytes per launch of that kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE,
         # profiles/README.md); only valid for the workload / dtype they were taken on
         traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r01h_pmc_traffic.json")
+        pmc_path = os.path.join(ROOT, "profiles", "r01j_pmc_traffic.json")
         if args.workload == "gemma2-2b" and args.dtype == "bf16" and not args.unit_norm and os.path.exists(pmc_path):
             with open(pmc_path) as f:
                 pmc = json.load(f)["kernels"]
