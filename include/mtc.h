@@ -79,6 +79,12 @@ int mtc_encode_fwd(const mtc_desc* d, const void* x, const void* W_encT, const v
 int mtc_encode_threshold_infer(const mtc_desc* d, const void* x, const void* W_encT, const void* b_enc,
                                const void* threshold, void* feats, void* stream);
 
+/* Encoder tile override (no counterpart in the reference: a tuning / test knob).  0 = automatic choice by problem
+ * size (default; the environment variable MTC_ENCODE_TILE = 1 | 2 is read once at the first launch), 1 = always the
+ * 128 x 128 MFMA kernel, 2 = always the 256 x 256 MFMA kernel (bf16, A_s a multiple of 64).  Returns the previous
+ * setting, or -1 for an invalid argument.  Process-wide; not synchronised with launches on other threads. */
+int mtc_encode_set_tile(int tile);
+
 /* a3  global batch-TopK (sae.py:176-187) as an exact k-th-largest threshold select over the
  * B*D activations; a5 threshold EMA input (sae.py:358-360) falls out as min_sel_bits.
  * Phases are separate entry points so a feature-sharded caller can all-reduce `hist` between

@@ -38,6 +38,7 @@ PROTOTYPES = {
     "mtc_row_normalize": (C.c_int, [DP, P, P, P, P, P]),
     "mtc_encode_fwd": (C.c_int, [DP, P, P, P, P, P]),
     "mtc_encode_threshold_infer": (C.c_int, [DP, P, P, P, P, P, P]),
+    "mtc_encode_set_tile": (C.c_int, [C.c_int]),
     "mtc_select_levels": (C.c_int, [DP]),
     "mtc_select_init": (C.c_int, [P, C.c_uint32, P]),
     "mtc_select_hist": (C.c_int, [DP, P, C.c_int, P, P, P]),

@@ -574,31 +574,59 @@ extern "C" int mtc_row_normalize(const mtc_desc* d, const void* x, void* x_norm,
     return check_launch("mtc_row_normalize");
 }
 
+// Tile choice and one-time kernel attributes.  The environment is read ONCE (first launch), the LDS opt-in of
+// each kernel is set once per device; mtc_encode_set_tile() overrides the choice at run time (tests force the
+// 256 x 256 kernel at small shapes through it).
+static int g_tile = -1;               // -1: not initialised; 0 auto, 1 = 128 x 128, 2 = 256 x 256
+static int g_f32_generic = -1;
+static void encode_options_once() {
+    if (g_tile < 0) {
+        const char* force = getenv("MTC_ENCODE_TILE");
+        g_tile = (force && (force[0] == '1' || force[0] == '2')) ? force[0] - '0' : 0;
+    }
+    if (g_f32_generic < 0) g_f32_generic = getenv("MTC_ENCODE_F32_GENERIC") ? 1 : 0;
+}
+constexpr int MAX_DEV = 64;
+static bool g_attr_done[3][MAX_DEV];
+static void lds_opt_in(int which, const void* fn, int lds) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+    if (dev >= 0 && dev < MAX_DEV && g_attr_done[which][dev]) return;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return;   // the launch reports it
+    if (dev >= 0 && dev < MAX_DEV) g_attr_done[which][dev] = true;
+}
+
+extern "C" int mtc_encode_set_tile(int tile) {
+    encode_options_once();
+    const int prev = g_tile;
+    MTC_REQUIRE(tile >= 0 && tile <= 2, "mtc_encode_set_tile: tile must be 0 (auto), 1 (128 x 128) or 2 (256 x 256)");
+    g_tile = tile;
+    return prev;
+}
+
 static int encode_impl(const mtc_desc* d, const void* x, const void* W_encT, const void* b_enc, const void* thr,
                        void* acts, void* stream) {
     const int M = d->B, N = d->D, K = d->A_s;
-    if (d->dtype == MTC_F32 && (K % BK32) == 0 && !(getenv("MTC_ENCODE_F32_GENERIC"))) {
+    encode_options_once();
+    if (d->dtype == MTC_F32 && (K % BK32) == 0 && !g_f32_generic) {
         const int lds = 2 * 2 * TILE_BYTES;
-        hipFuncSetAttribute(reinterpret_cast<const void*>(encode_f32_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        lds_opt_in(0, reinterpret_cast<const void*>(encode_f32_mfma_kernel), lds);
         const int mt = (M + BM - 1) / BM, nt = (N + BN - 1) / BN;
         hipLaunchKernelGGL(encode_f32_mfma_kernel, dim3(mt * nt), dim3(256), lds, as_stream(stream),
                            reinterpret_cast<const float*>(x), reinterpret_cast<const float*>(W_encT),
                            reinterpret_cast<const float*>(b_enc), reinterpret_cast<float*>(acts), M, N, K, mt, nt, thr);
         return check_launch("mtc_encode_fwd");
     }
-    const char* force = getenv("MTC_ENCODE_TILE");
     const int big_tiles = ((M + B2M - 1) / B2M) * ((N + B2N - 1) / B2N);
-    if (d->dtype == MTC_BF16 && (K % BK) == 0 && ((big_tiles >= 512 && !(force && force[0] == '1')) || (force && force[0] == '2'))) {
+    if (d->dtype == MTC_BF16 && (K % BK) == 0 && ((big_tiles >= 512 && g_tile != 1) || g_tile == 2)) {
         const int lds = 2 * 4 * HALF_BYTES;
-        hipFuncSetAttribute(reinterpret_cast<const void*>(encode_bf16_mfma256_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        lds_opt_in(1, reinterpret_cast<const void*>(encode_bf16_mfma256_kernel), lds);
         const int mt = (M + B2M - 1) / B2M, nt = (N + B2N - 1) / B2N;
         hipLaunchKernelGGL(encode_bf16_mfma256_kernel, dim3(mt * nt), dim3(512), lds, as_stream(stream),
                            (const u16*)x, (const u16*)W_encT, (const u16*)b_enc, (u16*)acts, M, N, K, mt, nt, thr);
     } else if (d->dtype == MTC_BF16 && (K % BK) == 0) {
         const int lds = 2 * 2 * TILE_BYTES;
-        hipFuncSetAttribute(reinterpret_cast<const void*>(encode_bf16_mfma_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        lds_opt_in(2, reinterpret_cast<const void*>(encode_bf16_mfma_kernel), lds);
         const int mt = (M + BM - 1) / BM, nt = (N + BN - 1) / BN;
         hipLaunchKernelGGL(encode_bf16_mfma_kernel, dim3(mt * nt), dim3(256), lds, as_stream(stream),
                            (const u16*)x, (const u16*)W_encT, (const u16*)b_enc, (u16*)acts, M, N, K, mt, nt, thr);

@@ -368,11 +368,11 @@ def lr_factor(scheduler_type: str, step: int, warmup_steps: int, total_steps: in
 
 
 # --------------------------------------------------------------------------- one whole train step
-def train_step(params, state, opt, x_source, x_target, cfg, lr: Optional[float] = None):
+def train_step(params, state, opt, x_source, x_target, cfg, lr: Optional[float] = None, acts_override=None):
     """forward -> analytic backward -> unit-norm projection -> Adam (training.py:172-179).
     ``opt`` = {"step": int, "m": {name: tensor}, "v": {name: tensor}}; returns (out, inter, grads)
-    and updates params/state/opt in place (dict entries rebound)."""
-    out, new, inter = forward(params, state, x_source, x_target, cfg, training=True)
+    and updates params/state/opt in place (dict entries rebound).  ``acts_override``: see forward()."""
+    out, new, inter = forward(params, state, x_source, x_target, cfg, training=True, acts_override=acts_override)
     grads32 = backward(params, x_source, x_target, cfg, inter)
     dt = params["W_enc"].dtype
     grads = {k: grads32[k].to(dt) for k in ("b_enc", "W_enc", "W_dec", "b_dec")}

@@ -363,7 +363,10 @@ def test_select_carry_is_identical_to_full_select(dt, gpu_lib):
     assert carry[0].item() == 0
 
 
-@pytest.mark.parametrize("dt,A", [(torch.bfloat16, 768), (torch.float32, 512), (torch.bfloat16, 2304)])
+@pytest.mark.parametrize("dt,A", [(torch.bfloat16, 768), (torch.float32, 512), (torch.bfloat16, 2304),
+                                  # NC = 3 / 7 / 9 / 16 chunks per lane (Gemma-2-9B: 3584, Gemma-2-27B: 4608)
+                                  (torch.bfloat16, 1536), (torch.bfloat16, 3584), (torch.float32, 3584),
+                                  (torch.bfloat16, 4608), (torch.float32, 4608), (torch.bfloat16, 8192)])
 def test_fused_backward_adam_equals_backward_then_adam(dt, A, gpu_lib):
     """The fused per-row {gradient -> [projection] -> Adam} kernels (and d_vals produced by the decoder kernel)
     against the materialised path:
