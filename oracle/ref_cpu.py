@@ -312,6 +312,9 @@ def backward(params, x_source, x_target, cfg, inter, grad_out: float = 1.0):
         g = g + g_aux
     g = g * grad_out
     g_raw = g * inter["std"].to(F32) if inter["std"] is not None else g
+    # the reference's autograd holds dL/dx_hat in the model dtype (x_hat is a dt tensor): one rounding here, which
+    # every gradient below inherits (a no-op for fp32 models)
+    g_raw = g_raw.to(dt).to(F32)
 
     db_dec = g_raw.sum(0)
     dW_dec = torch.zeros(D, A_t, dtype=F32).index_add(0, cols, vals[:, None] * g_raw[rows])

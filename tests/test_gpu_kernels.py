@@ -69,8 +69,10 @@ def check_against_oracle(cfg, params, cnt, xs, xt, res, hp):
             _close(res["xn"], inter["x_norm"], 8e-3, 1e-6, "x_norm")
         _close(res["mean"], inter["mean"].flatten(), 1e-5 if f32 else 8e-3, 1e-6, "mean")
         _close(res["std"], inter["std"].flatten(), 1e-5 if f32 else 8e-3, 1e-6, "std")
-    # a3 dense part: GEMM vs the oracle's own fp32 contraction (different summation order)
-    _close(acts_gpu, i_free["acts"], 1e-5 if f32 else 8e-3, 1e-5 if f32 else 1e-3, "acts")
+    # a3 dense part: GEMM vs the oracle's own fp32 contraction (different summation order: the fp32 bound grows with
+    # the square root of the contraction length; 1e-5 is the bar at K <= 768)
+    ks = max(1.0, (xs.shape[1] / 768.0) ** 0.5)
+    _close(acts_gpu, i_free["acts"], 1e-5 * ks if f32 else 8e-3, 1e-5 * ks if f32 else 1e-3, "acts")
     # a3 select: BIT-EXACT indices and values given identical activations
     sel = res["sel"]
     st = sel.state.cpu()

@@ -120,15 +120,18 @@ def _steps_vs_oracle(A, D, prefix, B, k, dt, unit, steps, min_frac, aux=False):
             if f32:
                 _close(got, ref, 0, 1e-2 * cfg["lr"] + 1e-7, f"{name} after step {i}")
                 continue
-            frac = float(((got - ref).abs() <= _exact_ulp(ref, -24)).float().mean())
-            report[(i, name)] = frac
             if name.startswith("W_"):
+                frac = float(((got - ref).abs() <= _exact_ulp(ref, -24)).float().mean())
                 assert frac >= min_frac, f"{name} after step {i}: only {frac:.5f} within 1 bf16 ulp of the oracle"
             else:
-                # biases start at zero: Adam turns a near-zero gradient whose sign flips under rounding into a full
-                # +-lr step, so a few entries differ by up to 2 lr per step; the bulk must still agree
-                assert frac >= 0.98, f"{name} after step {i}: {frac:.5f}"
+                # biases start at zero, so they ARE the sum of the Adam updates: the three bf16 roundings inside one
+                # update (m, sqrt(v) / sqrt(bc2), m / denom) show directly -- the bulk must agree within 4 ulps (about
+                # 1 % of an lr-sized update); a near-zero gradient whose sign flips under rounding turns into a full
+                # +-lr step, so single entries may differ by up to 2 lr per step
+                frac = float(((got - ref).abs() <= 4 * _exact_ulp(ref, -24)).float().mean())
+                assert frac >= 0.98, f"{name} after step {i}: {frac:.5f} within 4 ulps"
                 assert float((got - ref).abs().max()) <= 2.0 * (i + 1) * cfg["lr"] + 1e-6, name
+            report[(i, name)] = frac
     return report
 
 
@@ -222,7 +225,14 @@ def test_config2_full_size_encoder_and_select_against_oracle(gpu_lib):
                                    torch.randint(0, B, (256,), generator=g)]))
     assert rows.numel() >= 256
     want = R.encode_acts(xs[rows], params["W_enc"], params["b_enc"])
-    _close(acts_cpu[rows], want, 8e-3, 1e-3, "config #2 activations vs fp32 contraction")
+    # one bf16 ulp of the PRE-bias value (the first of the two roundings, sae.py:173): where pre and bias partly
+    # cancel, that ulp is larger than the result's own
+    err = (acts_cpu[rows].double() - want.double()).abs()
+    mag = want.double().abs() + params["b_enc"].double().abs()[None, :]
+    # two roundings (GEMM result, then + b_enc), each may flip by one ulp (2^-7 relative at worst) when the fp32 sums
+    # differ in their last bits: every entry within 2 ulps, 99.9 % within 1
+    assert bool((err <= 1e-3 + 1.6e-2 * mag).all()), f"config #2 activations: max {float(err.max()):.3e}"
+    assert float((err <= 1e-3 + 8e-3 * mag).double().mean()) >= 0.999
     # the bf16 results agree exactly except where the fp32 sums straddle a rounding boundary
     same = float((acts_cpu[rows] == want).float().mean())
     assert same > 0.98, same
@@ -287,13 +297,19 @@ def test_medium_fixture_through_hip_path(tag, gpu_lib):
         _close(out[key].float(), fx["out"][key].float(), rtol, atol, key)
         assert out[key].dtype == fx["out"][key].dtype, key
     _close(m.threshold.float(), fx["threshold_after"].float(), rtol, atol, "threshold")
-    a, b = float(out["transcoder_out"].double().sum()), float(fx["out_checksum"])
+    a, b = float(out["transcoder_out"].detach().double().sum()), float(fx["out_checksum"])
     assert abs(a - b) <= (1e-3 if f32 else 2.0) + 1e-4 * abs(b), ("transcoder_out checksum", a, b)
     out["loss"].backward()
     for n, p in m.named_parameters():
         a, b = float(p.grad.double().abs().sum()), float(fx["grad_abs_checksum"][n])
         assert math.isclose(a, b, rel_tol=1e-4 if f32 else 2e-2), (n, a, b)
-    _close(m.b_dec.grad, fx["db_dec"], 1e-4 if f32 else 5e-2, 1e-7 if f32 else 2e-6, "db_dec")
+    if f32:
+        _close(m.b_dec.grad, fx["db_dec"], 1e-4, 1e-7, "db_dec")
+    else:
+        # bf16: ~1 % of the selections differ inside the tau tie class (torch.topk's pick is not lowest-index), which
+        # moves whole reconstruction rows; the column sums are compared in norm
+        a, b = m.b_dec.grad.double().cpu(), fx["db_dec"].double()
+        assert float((a - b).norm() / b.norm()) <= 5e-2, float((a - b).norm() / b.norm())
     if f32:
         _close(m.b_enc.grad, fx["db_enc"], 1e-4, 1e-7, "db_enc")
         assert torch.equal((m.W_dec.grad.abs().sum(-1) > 0).cpu(), fx["grad_row_nonzero"]["W_dec"])
