@@ -503,6 +503,280 @@ __global__ __launch_bounds__(512, 1) void encode_bf16_mfma256_kernel(const u16* 
     }
 }
 
+// ------------------------------------------------------------------------------------------- K1 bf16 MFMA, 256x256 tile, persistent
+// Same tile, LDS image, phase schedule and MFMA order as encode_bf16_mfma256_kernel (bit-identical activations),
+// restructured around what the time-over-K measurement showed: at config #2 the k-loop of that kernel accounts for
+// 0.44 ms of its 0.58-0.65 ms; the rest is per-tile fixed cost (a cold prologue, an epilogue of 32 8-byte stores per
+// lane, ~1000 VALU instructions of rounding) paid 9 times per CU with nothing running beside it.  Here
+//   * ONE workgroup per CU walks its tiles (XCD-contiguous logical ids, stride = workgroups per XCD);
+//   * the LDS-DMA stream never stops: W / X stages of the NEXT tile's first k-tiles are issued in the last two
+//     k-steps of the current one (the stream is indexed by a running step counter, buffer = step parity), so only
+//     the first tile of a workgroup has a prologue;
+//   * the epilogue rounds / biases / ReLUs on packed pairs (v_cvt_pk_bf16_f32, v_pk_max_i16: ~3.5 VALU per value
+//     instead of ~9), transposes each wave's 64 x 128 block through a private 4 KiB LDS region (XOR-swizzled, no
+//     barrier) and writes it as 16-byte stores, four full 256-byte row segments per wave-instruction (the 8-byte
+//     stores wrote 32-byte partial lines: 1.6x the bytes at the fabric); the stores drain under the next tile's MFMAs.
+typedef __attribute__((ext_vector_type(2))) short short2v;
+
+// round(round(acc) + bias), ReLU, for a pair of values, packed as two bf16 (sae.py:173-174)
+template <bool THR>
+__device__ __forceinline__ uint32_t bias_relu_pack2(float v0, float v1, float b0, float b1, float fl) {
+    const uint32_t p = pack2_bf16(v0, v1);                                         // first rounding: the GEMM result
+    const uint32_t q = pack2_bf16(__uint_as_float(p << 16) + b0, __uint_as_float(p & 0xffff0000u) + b1);   // second: + b_enc
+    if (!THR) {
+        // ReLU on the packed pair: a signed 16-bit max with 0 clears negative values and -0.0 (the select reads bit patterns)
+        const short2v z = {0, 0};
+        return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(short2v, q), z));
+    }
+    const float y0 = __uint_as_float(q << 16), y1 = __uint_as_float(q & 0xffff0000u);
+    return (y0 > fl ? (q & 0xffffu) : 0u) | (y1 > fl ? (q & 0xffff0000u) : 0u);
+}
+
+__device__ __forceinline__ void lid_to_tile(int lid, int mt, int nt, int& tm, int& tn) {
+    constexpr int GROUP = 4;     // logical ids walk GROUP-wide groups of batch tiles under each feature tile (see xcd_tile_coords)
+    const int per_group = GROUP * nt;
+    const int g = lid / per_group;
+    const int first_m = g * GROUP;
+    const int gsz = min(mt - first_m, GROUP);
+    const int in = lid - g * per_group;
+    tm = first_m + in % gsz;
+    tn = in / gsz;
+}
+
+#ifdef MTC_ENCODE_STAMPS
+// Diagnostic build only (tools/encode_stamps.sh builds a separate libmtc_diag.so): per-wave cycle accounting of the
+// persistent encoder.  Stamp values go to a buffer of their own; no output value depends on them.
+__device__ unsigned long long g_enc_stamps[2 * 256 * 8 * 8];
+#define STAMP() __builtin_amdgcn_s_memtime()
+#endif
+
+constexpr int STG_BYTES = 4096;                 // per-wave epilogue staging: 16 batch rows x 128 features x 2 B
+constexpr int P256_LDS = 2 * 4 * HALF_BYTES + 8 * STG_BYTES;     // 160 KiB: the whole LDS of a CU
+
+#ifdef MTC_ENCODE_STAMPS
+#define PFENCE(i) do { PHASE_FENCE(); { const unsigned long long t_ = STAMP(); t_iv[i] += t_ - t_prev; t_prev = t_; } } while (0)
+#else
+#define PFENCE(i) PHASE_FENCE()
+#endif
+
+template <bool THR>
+__global__ __launch_bounds__(512, 1) void encode_bf16_mfma256p_kernel(const u16* __restrict__ X, const u16* __restrict__ Wt,
+                                                                      const u16* __restrict__ bias, u16* __restrict__ acts,
+                                                                      int M, int N, int K, int mt, int nt, const void* __restrict__ thr) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3;
+    // ---- this workgroup's tiles: logical ids first, first + stride, ... (count of them)
+    const int tiles = mt * nt, G = gridDim.x, bid = blockIdx.x;
+    int first, stride, count;
+    if ((G & 7) == 0) {
+        // blocks b, b+8, ... share an XCD (speed only): each XCD walks a contiguous range of logical ids
+        const int q = tiles >> 3, r = tiles & 7, xcd = bid & 7, j = bid >> 3, gx = G >> 3;
+        const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        const int cnt = q + (xcd < r ? 1 : 0);
+        first = start + j; stride = gx;
+        count = j < cnt ? (cnt - j + gx - 1) / gx : 0;
+    } else {
+        first = bid; stride = G;
+        count = bid < tiles ? (tiles - bid + G - 1) / G : 0;
+    }
+    if (count == 0) return;                                                      // whole workgroup: no barrier entered yet
+    const int ktiles = K / BK;
+    const int S = count * ktiles;                                                // k-steps of this workgroup, all tiles
+#ifdef MTC_ENCODE_STAMPS
+    const unsigned long long t_start = STAMP(), rt_start = __builtin_amdgcn_s_memrealtime();
+    unsigned long long t_epi = 0, t_first_wait = 0, t_other_wait = 0, t_loop0 = 0, t_first_bar = 0;
+    bool after_epi = false;
+    unsigned long long t_iv[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0;
+#endif
+
+    // ---- staging: half-tile h has 16 pieces of 8 rows x 128 B; wave wid moves pieces 2 wid, 2 wid + 1 of every half
+    const int prow0 = (wid * 2) * 8 + (lane >> 3), prow1 = prow0 + 8;            // row inside a half-tile
+    const int pch0 = ((lane & 7) ^ ((prow0 >> 1) & 7)) * 8, pch1 = ((lane & 7) ^ ((prow1 >> 1) & 7)) * 8;
+    const u16* wsrc[2][2];
+    const u16* xsrc[2][2];
+    auto set_w = [&](int lid) {
+        int tm, tn;
+        lid_to_tile(lid, mt, nt, tm, tn);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            wsrc[h][0] = Wt + (size_t)min(tn * B2N + h * 128 + prow0, N - 1) * K + pch0;     // clamp: tails read valid rows
+            wsrc[h][1] = Wt + (size_t)min(tn * B2N + h * 128 + prow1, N - 1) * K + pch1;
+        }
+    };
+    auto set_x = [&](int lid) {
+        int tm, tn;
+        lid_to_tile(lid, mt, nt, tm, tn);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            xsrc[h][0] = X + (size_t)min(tm * B2M + h * 128 + prow0, M - 1) * K + pch0;
+            xsrc[h][1] = X + (size_t)min(tm * B2M + h * 128 + prow1, M - 1) * K + pch1;
+        }
+    };
+    auto stage_w = [&](int buf, int h, int kt) {
+        char* base = smem + buf * 4 * HALF_BYTES + h * HALF_BYTES + wid * 2 * 1024;
+        glds16(wsrc[h][0] + kt * BK, base);
+        glds16(wsrc[h][1] + kt * BK, base + 1024);
+    };
+    auto stage_x = [&](int buf, int h, int kt) {
+        char* base = smem + buf * 4 * HALF_BYTES + (2 + h) * HALF_BYTES + wid * 2 * 1024;
+        glds16(xsrc[h][0] + kt * BK, base);
+        glds16(xsrc[h][1] + kt * BK, base + 1024);
+    };
+    // the two operand streams run ahead of the MFMAs by one (W) / two (X) k-steps and cross tile boundaries
+    int wk = 0, wm = 0, xk = 0, xm = 0;                                           // next stage to issue: k-tile, tile ordinal
+    auto adv_w = [&]() { if (++wk == ktiles) { wk = 0; if (++wm < count) set_w(first + wm * stride); } };
+    auto adv_x = [&]() { if (++xk == ktiles) { xk = 0; if (++xm < count) set_x(first + xm * stride); } };
+
+    const int fr = lane & 15, fq = lane >> 4;
+    const int swz = (fr >> 1) & 7;
+    int off[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) off[ks] = fr * 128 + (((ks * 4 + fq) ^ swz) << 4);
+    const int w_base = wr * HALF_BYTES;                                          // this wave's W half-tile
+    const int x_base = (2 + (wc >> 1)) * HALF_BYTES + (wc & 1) * 64 * 128;     // its 64 batch rows
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 wf[2][4], xa[2][2], xb[2][2];
+
+    // prologue (first tile only): step 0 entirely, plus the X halves of step 1
+    set_w(first); set_x(first);
+    stage_w(0, 0, 0); stage_w(0, 1, 0); adv_w();
+    stage_x(0, 0, 0); stage_x(0, 1, 0); adv_x();
+    if (S > 1) {
+        stage_x(1, 0, xk); stage_x(1, 1, xk); adv_x();
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    PHASE_FENCE();
+    if (wr == 1) PHASE_FENCE();                                                  // stagger the second wave group
+
+    const float fl = epilogue_floor<MTC_BF16>(thr);
+    char* stg = smem + 2 * 4 * HALF_BYTES + wid * STG_BYTES;
+    int kt = 0, cm = 0;
+#ifdef MTC_ENCODE_STAMPS
+    t_loop0 = STAMP();
+    t_prev = t_loop0;
+#endif
+    for (int it = 0; it < S; ++it) {
+        const char* cur = smem + (it & 1) * 4 * HALF_BYTES;
+        const int nb = (it + 1) & 1;
+        const bool more = it + 1 < S, more2 = it + 2 < S;
+        // ---------------- phase 0
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) xa[ks][j] = *reinterpret_cast<const bf16x8*>(cur + x_base + j * 16 * 128 + off[ks]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wf[ks][i] = *reinterpret_cast<const bf16x8*>(cur + w_base + i * 16 * 128 + off[ks]);
+        }
+        if (more) stage_w(nb, 0, wk);
+        PFENCE(0);
+        mfma_quadrant<0, 0>(wf, xa, acc);
+        PFENCE(1);
+        // ---------------- phase 1
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) xb[ks][j] = *reinterpret_cast<const bf16x8*>(cur + x_base + (2 + j) * 16 * 128 + off[ks]);
+        if (more) { stage_w(nb, 1, wk); adv_w(); }
+        PFENCE(2);
+        mfma_quadrant<0, 2>(wf, xb, acc);
+        PFENCE(3);
+        // ---------------- phase 2
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wf[ks][i] = *reinterpret_cast<const bf16x8*>(cur + w_base + (4 + i) * 16 * 128 + off[ks]);
+        PFENCE(4);
+        mfma_quadrant<4, 2>(wf, xb, acc);
+        PFENCE(5);
+        // ---------------- phase 3
+#ifdef MTC_ENCODE_STAMPS
+        const unsigned long long tw0 = STAMP();
+#endif
+        if (more2) {
+            stage_x(it & 1, 0, xk); stage_x(it & 1, 1, xk); adv_x();
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                     // everything older (all of step it+1, earlier stores) is done
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+#ifdef MTC_ENCODE_STAMPS
+        const unsigned long long tw1 = STAMP();
+#endif
+        PFENCE(6);
+#ifdef MTC_ENCODE_STAMPS
+        const unsigned long long tw2 = STAMP();
+        if (after_epi) { t_first_wait += tw1 - tw0; t_first_bar += tw2 - tw1; } else t_other_wait += tw2 - tw0;
+        after_epi = false;
+#endif
+        mfma_quadrant<4, 0>(wf, xa, acc);
+        PFENCE(7);
+        if (++kt < ktiles) continue;
+#ifdef MTC_ENCODE_STAMPS
+        const unsigned long long te0 = STAMP();
+#endif
+        // ---------------- tile done: epilogue (no barrier; the next tile's first stages are already in flight)
+        kt = 0;
+        int tm, tn;
+        lid_to_tile(first + cm * stride, mt, nt, tm, tn);
+        ++cm;
+        const int fcol = tn * B2N + wr * 128;                                    // first feature of this wave's block
+        const int brow = tm * B2M + wc * 64;                                     // first batch row of it
+        uint2 bb[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int f = fcol + i * 16 + fq * 4;
+            bb[i] = f < N ? *reinterpret_cast<const uint2*>(bias + f) : uint2{0u, 0u};   // N % 8 == 0 -> in bounds, aligned
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // lane holds features i*16 + fq*4 + (0..3) of batch row j*16 + fr: 8 bytes into row fr of the staging block,
+            // 16-byte chunk (2 i + fq/2) XOR-ed with the row (conflict-free ds_write_b64 / ds_read_b128)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const f32x4 v = acc[i][j];
+                uint2 o;
+                o.x = bias_relu_pack2<THR>(v[0], v[1], bf16_bits_to_f32(bb[i].x & 0xffffu), bf16_bits_to_f32(bb[i].x >> 16), fl);
+                o.y = bias_relu_pack2<THR>(v[2], v[3], bf16_bits_to_f32(bb[i].y & 0xffffu), bf16_bits_to_f32(bb[i].y >> 16), fl);
+                *reinterpret_cast<uint2*>(stg + fr * 256 + ((((i << 1) | (fq >> 1)) ^ fr) << 4) + ((fq & 1) << 3)) = o;
+                acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // wave-private region: no barrier needed
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int R = (lane >> 4) + 4 * s, c = lane & 15;
+                const u32x4 val = *reinterpret_cast<const u32x4*>(stg + R * 256 + ((c ^ R) << 4));
+                const int b = brow + j * 16 + R, f = fcol + c * 8;
+                if (b < M && f < N) *reinterpret_cast<u32x4*>(acts + (size_t)b * N + f) = val;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // reads done before the next round overwrites
+        }
+#ifdef MTC_ENCODE_STAMPS
+        t_epi += STAMP() - te0;
+        t_prev = STAMP();
+        after_epi = true;
+#endif
+    }
+    if (wr == 0) PHASE_FENCE();                                                  // pair group 1's last barrier
+#ifdef MTC_ENCODE_STAMPS
+    if (lane == 0) {
+        unsigned long long* o = g_enc_stamps + ((size_t)(bid & 255) * 8 + wid) * 8;
+        const unsigned long long t_end = STAMP();
+        o[0] = t_end - t_start; o[1] = t_loop0 - t_start; o[2] = t_epi; o[3] = t_first_wait; o[4] = t_other_wait;
+        o[5] = __builtin_amdgcn_s_memrealtime() - rt_start; o[6] = t_first_bar; o[7] = (unsigned long long)count;
+        unsigned long long* o2 = g_enc_stamps + 256 * 8 * 8 + ((size_t)(bid & 255) * 8 + wid) * 8;
+        for (int i = 0; i < 8; ++i) o2[i] = t_iv[i];
+    }
+#endif
+}
+
 // ------------------------------------------------------------------------------------------- K1 generic
 // Any shape / dtype (fp32 model dtype, and bf16 shapes whose K is not a multiple of 64).
 // 64x64 tile, 16-deep k slices, 4x4 outputs per thread, fp32 FMA.
@@ -582,12 +856,13 @@ static int g_f32_generic = -1;
 static void encode_options_once() {
     if (g_tile < 0) {
         const char* force = getenv("MTC_ENCODE_TILE");
-        g_tile = (force && (force[0] == '1' || force[0] == '2')) ? force[0] - '0' : 0;
+        g_tile = (force && force[0] >= '1' && force[0] <= '3') ? force[0] - '0' : 0;
     }
     if (g_f32_generic < 0) g_f32_generic = getenv("MTC_ENCODE_F32_GENERIC") ? 1 : 0;
 }
 constexpr int MAX_DEV = 64;
-static bool g_attr_done[3][MAX_DEV];
+static bool g_attr_done[5][MAX_DEV];
+static int g_cus[MAX_DEV];
 static void lds_opt_in(int which, const void* fn, int lds) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = -1;
@@ -596,10 +871,26 @@ static void lds_opt_in(int which, const void* fn, int lds) {
     if (dev >= 0 && dev < MAX_DEV) g_attr_done[which][dev] = true;
 }
 
+static int cu_count() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return 256;
+    if (g_cus[dev] == 0) {
+        int n = 0;
+        g_cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    return g_cus[dev];
+}
+
+#ifdef MTC_ENCODE_STAMPS
+extern "C" int mtc_diag_read_encode_stamps(unsigned long long* host, size_t n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_enc_stamps), n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 extern "C" int mtc_encode_set_tile(int tile) {
     encode_options_once();
     const int prev = g_tile;
-    MTC_REQUIRE(tile >= 0 && tile <= 2, "mtc_encode_set_tile: tile must be 0 (auto), 1 (128 x 128) or 2 (256 x 256)");
+    MTC_REQUIRE(tile >= 0 && tile <= 3, "mtc_encode_set_tile: tile must be 0 (auto), 1 (128 x 128), 2 (256 x 256) or 3 (256 x 256, one tile per workgroup)");
     g_tile = tile;
     return prev;
 }
@@ -618,12 +909,25 @@ static int encode_impl(const mtc_desc* d, const void* x, const void* W_encT, con
         return check_launch("mtc_encode_fwd");
     }
     const int big_tiles = ((M + B2M - 1) / B2M) * ((N + B2N - 1) / B2N);
-    if (d->dtype == MTC_BF16 && (K % BK) == 0 && ((big_tiles >= 512 && g_tile != 1) || g_tile == 2)) {
+    if (d->dtype == MTC_BF16 && (K % BK) == 0 && g_tile == 3) {
+        // the round-1 one-tile-per-workgroup kernel, kept for A/B timing against the persistent one
         const int lds = 2 * 4 * HALF_BYTES;
         lds_opt_in(1, reinterpret_cast<const void*>(encode_bf16_mfma256_kernel), lds);
         const int mt = (M + B2M - 1) / B2M, nt = (N + B2N - 1) / B2N;
         hipLaunchKernelGGL(encode_bf16_mfma256_kernel, dim3(mt * nt), dim3(512), lds, as_stream(stream),
                            (const u16*)x, (const u16*)W_encT, (const u16*)b_enc, (u16*)acts, M, N, K, mt, nt, thr);
+    } else if (d->dtype == MTC_BF16 && (K % BK) == 0 && ((big_tiles >= 512 && g_tile != 1) || g_tile == 2)) {
+        const int mt = (M + B2M - 1) / B2M, nt = (N + B2N - 1) / B2N;
+        const int grid = min(mt * nt, cu_count());                               // one persistent workgroup per CU
+        if (thr) {
+            lds_opt_in(3, reinterpret_cast<const void*>(encode_bf16_mfma256p_kernel<true>), P256_LDS);
+            hipLaunchKernelGGL(encode_bf16_mfma256p_kernel<true>, dim3(grid), dim3(512), P256_LDS, as_stream(stream),
+                               (const u16*)x, (const u16*)W_encT, (const u16*)b_enc, (u16*)acts, M, N, K, mt, nt, thr);
+        } else {
+            lds_opt_in(4, reinterpret_cast<const void*>(encode_bf16_mfma256p_kernel<false>), P256_LDS);
+            hipLaunchKernelGGL(encode_bf16_mfma256p_kernel<false>, dim3(grid), dim3(512), P256_LDS, as_stream(stream),
+                               (const u16*)x, (const u16*)W_encT, (const u16*)b_enc, (u16*)acts, M, N, K, mt, nt, thr);
+        }
     } else if (d->dtype == MTC_BF16 && (K % BK) == 0) {
         const int lds = 2 * 2 * TILE_BYTES;
         lds_opt_in(2, reinterpret_cast<const void*>(encode_bf16_mfma_kernel), lds);

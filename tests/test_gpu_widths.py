@@ -146,7 +146,10 @@ def test_three_steps_bf16_vs_oracle_shared_activations(unit, gpu_lib):
 
 
 # ------------------------------------------------------------------ (b) the 256 x 256 MFMA encoder, forced
-@pytest.mark.parametrize("B,A,D", [(300, 768, 1000), (520, 2304, 776), (64, 2304, 264)])
+@pytest.mark.parametrize("B,A,D", [(300, 768, 1000), (520, 2304, 776), (64, 2304, 264),
+                                   # 3 x 101 = 303 tiles on 256 persistent workgroups: some walk two tiles, some one;
+                                   # 1800 x 64 tiles: every workgroup walks 7 (K = 64: one k-step per tile)
+                                   (520, 128, 25608), (2048, 64, 57344)])
 def test_encoder_256_tile_against_oracle(B, A, D, gpu_lib, force_tile):
     """encode_bf16_mfma256_kernel at ragged shapes (partial batch tiles, partial feature tiles, D % 256 != 0), K = 768
     (12 k-tiles) and K = 2304 (36 k-tiles: the production staging schedule), against the oracle's fp32 contraction,
@@ -167,7 +170,11 @@ def test_encoder_256_tile_against_oracle(B, A, D, gpu_lib, force_tile):
     torch.cuda.synchronize()
     assert torch.equal(big, small), "256 x 256 and 128 x 128 encoders must agree bit for bit"
     want = R.encode_acts(x, W, b)
-    _close(big, want, 8e-3, 1e-3, "acts (256 x 256 kernel) vs fp32 contraction")
+    # two roundings (GEMM result, + b_enc): every entry within 2 bf16 ulps of the fp32 contraction, 99.9 % within 1
+    err = (big.cpu().double() - want.double()).abs()
+    mag = want.double().abs() + b.double().abs()[None, :]
+    assert bool((err <= 1e-3 + 1.6e-2 * mag).all()), f"acts (256 x 256 kernel) vs fp32 contraction: max {float(err.max()):.3e}"
+    assert float((err <= 1e-3 + 8e-3 * mag).double().mean()) >= 0.999
     assert float((big.cpu() > 0).float().mean()) > 0.3          # not a degenerate all-zero comparison
     for thr in (0.4, 0.0, float("nan")):
         t = torch.tensor(thr, dtype=dt, device=DEV)

@@ -39,12 +39,13 @@ def main():
     ap.add_argument("--zeros", action="store_true", help="all-zero operands (clock held on trivial data)")
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--blas", action="store_true")
-    ap.add_argument("--gap-ms", type=float, default=0.0, help="idle gap between launches (host sleep)")
+    ap.add_argument("--A", type=int, default=0, help="override the contraction length (slope / intercept of time over K)")
     args = ap.parse_args()
     from matryoshka_transcoder_amd.engine import HotPath
     from matryoshka_transcoder_amd import _lib
     torch.cuda.set_device(0)
     A, groups, k, B = bench.WORKLOADS[args.workload]
+    A = args.A or A
     D = sum(groups)
     dt = torch.bfloat16
     g = torch.Generator("cpu").manual_seed(0)
