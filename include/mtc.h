@@ -238,6 +238,16 @@ int mtc_backward_sparse(const mtc_desc* d, const int32_t* col_ptr, const int32_t
 size_t mtc_colsum_workspace_bytes(const mtc_desc* d);
 int mtc_colsum(const mtc_desc* d, const void* g, const float* scale, void* workspace,
                size_t workspace_bytes, void* db_dec, int accumulate, void* stream);
+/* No counterpart in the reference: the ONE entry point of this library that allocates nothing and takes no
+ * workspace, for callers that cannot call hipMalloc (code under HIP graph capture, tight serving loops, harnesses
+ * that forbid allocation).  Same result, bit for bit, as mtc_colsum (db_dec = scale * sum_b g_b, sae.py:217-245
+ * backward); the per-slab partial sums live in a static device array inside the library (64 slabs x 8192 columns
+ * fp32 = 2 MiB, held by every GPU the library runs on until the process ends).  A_t > 8192 is rejected with an error.
+ * The array's device address is looked up on the first call on each device (hipGetSymbolAddress; make that first
+ * call outside a graph capture).  All calls on one GPU share the array: calls that overlap on one GPU (different
+ * streams) race; nothing needs clearing between calls (every partial read is written by the same call). */
+int mtc_colsum_static(const mtc_desc* d, const void* g, const float* scale, void* db_dec, int accumulate,
+                      void* stream);
 
 /* a12 + a13  make_decoder_weights_and_grad_unit_norm (sae.py:155-163) fused with torch.optim.Adam
  * (training.py:60,178; betas, eps 1e-8, no weight decay), op-by-op rounding in the parameter

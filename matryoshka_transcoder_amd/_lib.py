@@ -67,6 +67,7 @@ PROTOTYPES = {
     "mtc_backward_sparse": (C.c_int, [DP, P, P, P, P, P, P, P, P, P, P, P, C.c_int, P]),
     "mtc_colsum_workspace_bytes": (C.c_size_t, [DP]),
     "mtc_colsum": (C.c_int, [DP, P, P, P, C.c_size_t, P, C.c_int, P]),
+    "mtc_colsum_static": (C.c_int, [DP, P, P, P, C.c_int, P]),
     "mtc_unitnorm_adam_rows": (C.c_int, [DP, P, P, P, P, HP, C.c_int, P]),
     "mtc_adam_flat": (C.c_int, [C.c_int32, C.c_size_t, P, P, P, P, HP, P]),
     "mtc_fused_backward_adam_dec": (C.c_int, [DP, P, P, P, P, P, P, P, P, P, HP, P, C.c_float, P]),

@@ -272,6 +272,14 @@ __global__ __launch_bounds__(256) void colsum_finish_kernel(int A, int slabs, co
     D_::st(p, accumulate ? D_::ld(p) + s : s);
 }
 
+// ---------------------------------------------------------------- scratch of mtc_colsum_static
+// The one entry point that allocates nothing (include/mtc.h): its per-slab partial sums live in this file-scope
+// array instead of a caller workspace.  Every GPU the library runs on holds its own copy (2 MiB) until the process
+// ends.  In host code the array's NAME is only a stand-in for the symbol, not a device address: the address is
+// looked up once per device with hipGetSymbolAddress and only that pointer is ever handed to a kernel.
+constexpr int COLSUM_STATIC_MAX_A = 8192;
+static __device__ __align__(256) float colsum_scratch[COLSUM_SLABS * COLSUM_STATIC_MAX_A];
+
 }  // namespace mtc
 
 using namespace mtc;
@@ -364,24 +372,56 @@ extern "C" int mtc_backward_sparse(const mtc_desc* d, const int32_t* col_ptr, co
 
 extern "C" size_t mtc_colsum_workspace_bytes(const mtc_desc* d) { return d ? COLSUM_SLABS * (size_t)d->A_t * sizeof(float) : 0; }
 
+static void colsum_launch(const mtc_desc* d, const void* g, const float* scale, float* workspace, void* db_dec, int accumulate,
+                          hipStream_t s);
+
 extern "C" int mtc_colsum(const mtc_desc* d, const void* g, const float* scale, void* workspace, size_t workspace_bytes,
                           void* db_dec, int accumulate, void* stream) {
     if (check_desc(d, "mtc_colsum")) return -1;
     MTC_REQUIRE(g && workspace && db_dec, "mtc_colsum: null pointer");
     MTC_REQUIRE(workspace_bytes >= mtc_colsum_workspace_bytes(d), "mtc_colsum: workspace too small");
+    colsum_launch(d, g, scale, reinterpret_cast<float*>(workspace), db_dec, accumulate, as_stream(stream));
+    return check_launch("mtc_colsum");
+}
+
+// Same kernels, scratch in the library's static device array: no hipMalloc / hipFree / allocating call on this path.
+// The per-device address of the array is looked up on the first call on each device (with that device current).
+// Every partial the finish kernel reads is written by the partial kernel of the same call, so nothing has to be
+// cleared between calls; calls that overlap on one GPU (two streams) share the array and race.
+constexpr int STATIC_MAX_DEV = 64;
+static float* g_colsum_scratch_ptr[STATIC_MAX_DEV];
+extern "C" int mtc_colsum_static(const mtc_desc* d, const void* g, const float* scale, void* db_dec, int accumulate,
+                                 void* stream) {
+    if (check_desc(d, "mtc_colsum_static")) return -1;
+    MTC_REQUIRE(g && db_dec, "mtc_colsum_static: null pointer");
+    MTC_REQUIRE(d->A_t <= COLSUM_STATIC_MAX_A,
+                "mtc_colsum_static: A_t = %d exceeds the static scratch (at most %d columns); use mtc_colsum with a workspace",
+                d->A_t, COLSUM_STATIC_MAX_A);
+    int dev = -1;
+    MTC_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < STATIC_MAX_DEV, "mtc_colsum_static: no current device");
+    if (!g_colsum_scratch_ptr[dev]) {
+        float* ptr = nullptr;
+        const hipError_t e = hipGetSymbolAddress(reinterpret_cast<void**>(&ptr), HIP_SYMBOL(colsum_scratch));
+        MTC_REQUIRE(e == hipSuccess && ptr, "mtc_colsum_static: hipGetSymbolAddress failed (%s)", hipGetErrorString(e));
+        g_colsum_scratch_ptr[dev] = ptr;
+    }
+    colsum_launch(d, g, scale, g_colsum_scratch_ptr[dev], db_dec, accumulate, as_stream(stream));
+    return check_launch("mtc_colsum_static");
+}
+
+static void colsum_launch(const mtc_desc* d, const void* g, const float* scale, float* workspace, void* db_dec, int accumulate,
+                          hipStream_t s) {
     const int slabs = COLSUM_SLABS, rows_per = (d->B + slabs - 1) / slabs;
-    hipStream_t s = as_stream(stream);
     if (d->dtype == MTC_BF16)
         hipLaunchKernelGGL(colsum_partial_kernel<MTC_BF16>, dim3((d->A_t / 8 + 63) / 64, slabs), dim3(256), 0, s, d->B, d->A_t, g,
-                           rows_per, reinterpret_cast<float*>(workspace));
+                           rows_per, workspace);
     else
         hipLaunchKernelGGL(colsum_partial_kernel<MTC_F32>, dim3((d->A_t / 8 + 63) / 64, slabs), dim3(256), 0, s, d->B, d->A_t, g,
-                           rows_per, reinterpret_cast<float*>(workspace));
+                           rows_per, workspace);
     if (d->dtype == MTC_BF16)
         hipLaunchKernelGGL(colsum_finish_kernel<MTC_BF16>, dim3((d->A_t + 255) / 256), dim3(256), 0, s, d->A_t, slabs,
                            reinterpret_cast<const float*>(workspace), scale, db_dec, accumulate);
     else
         hipLaunchKernelGGL(colsum_finish_kernel<MTC_F32>, dim3((d->A_t + 255) / 256), dim3(256), 0, s, d->A_t, slabs,
                            reinterpret_cast<const float*>(workspace), scale, db_dec, accumulate);
-    return check_launch("mtc_colsum");
 }
