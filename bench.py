@@ -63,13 +63,15 @@ def batch_pool(B, A, dtype, device, n=8):
     return pool
 
 
-def cpu_baseline(workload, dtype, budget_rows=512, steps=64):
-    """Reference algorithm on the host cores: oracle.DenseStep (same ATen call sequence as the
-    reference's step), on a bounded sample = `steps` steps at B=budget_rows of the same shapes."""
+def cpu_baseline(workload, dtype, budget_rows=None, steps=3):
+    """Reference algorithm on the host cores: oracle.DenseStep (same ATen call sequence as the reference's step;
+    timed next to the imported reference itself in profiles/r02_cpu_reference.json), at the metric's own batch size
+    (config #2 for 3 steps).  The sample is bounded: the step count shrinks if a step is slow."""
     from oracle import ref_cpu as R
     cores = min(16, os.cpu_count() or 1)
     torch.set_num_threads(cores)
-    cfg, _ = make_cfg(workload, dtype, "cpu")
+    cfg, B = make_cfg(workload, dtype, "cpu")
+    budget_rows = budget_rows or B
     A = cfg["act_size"]
     model = R.DenseStep(cfg)
     pool = batch_pool(budget_rows, A, dtype, "cpu", n=2)
@@ -136,6 +138,32 @@ def stage_times(tc, opt, pool, reps=5):
     return out
 
 
+def launch_ranks(n):
+    """One child process per rank over torch.distributed.run (rendezvous on 127.0.0.1, a free port); rank 0's JSON
+    line comes out on this process's stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def launch_test():
+    """MTC_BENCH_LAUNCH_TEST=1 (tests/test_host_logic.py, no GPU): every rank joins a gloo group and rank 0 prints the
+    one JSON line with the world size it saw -- proves the launcher, the rendezvous and the single-line contract."""
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    t = torch.ones(1)
+    dist.all_reduce(t)
+    if dist.get_rank() == 0:
+        print(json.dumps({"launch_test": True, "n_gpus": dist.get_world_size(), "ranks_seen": int(t.item())}))
+    dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -148,6 +176,17 @@ def main():
     ap.add_argument("--sharded", action="store_true", help="use the feature-sharded classes even on one GPU (overhead check)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N`: start N ranks (one per GPU) through torch.distributed.run and pass its exit code on.
+        # This parent has not touched the GPU (nothing above initialises HIP) and never does.
+        sys.exit(launch_ranks(args.gpus))
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}: launch one rank per GPU "
+              f"(python bench.py --gpus N does that itself)", file=sys.stderr)
+        sys.exit(2)
+    if os.environ.get("MTC_BENCH_LAUNCH_TEST"):
+        sys.exit(launch_test())
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -156,6 +195,7 @@ def main():
     dev_index = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(dev_index)
     device = f"cuda:{dev_index}"
+    collective_backend = None
     if world > 1 or args.sharded:
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:
@@ -174,6 +214,8 @@ def main():
                 dist.init_process_group("nccl", device_id=torch.device(device))
             dist.barrier()
             torch.cuda.synchronize()
+            collective_backend = dist.get_backend()
+            world = dist.get_world_size()
         finally:
             sys.stdout.flush()
             os.dup2(saved_fd, 1)
@@ -228,6 +270,8 @@ def main():
         "config": {"workload": f"{args.workload}: act {A}, dict {D}, cumulative prefixes {cfg['prefix_sizes']}, "
                                f"top_k {k}, batch {B}, input_unit_norm {args.unit_norm}",
                    "global_batch": B, "parallelism": "single GPU" if world == 1 else f"dictionary sharded x{world}",
+                   "collective_world": world if (world > 1 or args.sharded) else None,
+                   "collective_backend": collective_backend,
                    "final_loss": float(out["loss"].detach().float()), "final_l0": float(out["l0_norm"].detach())},
     }
     if rank == 0 and world == 1 and not args.sharded:

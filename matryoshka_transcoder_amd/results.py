@@ -5,8 +5,10 @@
                                     /metrics.json | metrics/step_N.json
 
 `state_dict()` keys, shapes and dtypes are the reference's (b_enc, W_enc, W_dec, b_dec, threshold).
-What the reference does not persist (optimizer moments, step, dead counters) goes to a side file
-`checkpoints/{name}.extra.pt` so that the reference layout stays loadable by the reference.
+What the reference does not persist goes to a side file `checkpoints/{name}.extra.pt`, so that the reference layout
+stays loadable by the reference: always `step` and the dead counters (`num_batches_not_active`), plus the optimizer's
+`state_dict()` (Adam moments and step counts) when `save_checkpoint` is given the optimizer -- `train_transcoder`
+passes it.  `load_extra` restores all of it (tensors only, `weights_only=True`): a resumed run continues bit for bit.
 """
 from __future__ import annotations
 
@@ -48,7 +50,7 @@ class CleanResultsManager:
     # -- writers -------------------------------------------------------------------------------------------
     def save_checkpoint(self, experiment_dir: Path, model: torch.nn.Module, config: Dict[str, Any], step: int,
                         metrics: Optional[Dict[str, Any]] = None, is_final: bool = False,
-                        extra: Optional[Dict[str, Any]] = None) -> None:
+                        extra: Optional[Dict[str, Any]] = None, optimizer: Optional[torch.optim.Optimizer] = None) -> None:
         run = Path(experiment_dir)
         stem = "final" if is_final else f"step_{step}"
         weights = run / "checkpoints" / f"{stem}.pt"
@@ -57,6 +59,9 @@ class CleanResultsManager:
         torch.save({name: t.detach().contiguous() for name, t in model.state_dict().items()}, weights)
         if extra is None and hasattr(model, "num_batches_not_active"):
             extra = {"step": step, "num_batches_not_active": model.num_batches_not_active.detach().clone()}
+        if optimizer is not None:
+            extra = dict(extra or {"step": step})
+            extra["optimizer"] = optimizer.state_dict()
         if extra:
             torch.save(extra, weights.with_name(f"{stem}.extra.pt"))
         cfg_out = dict(config)
@@ -76,6 +81,23 @@ class CleanResultsManager:
         sample_collector.save_samples(str(target), top_k_features, samples_per_feature)
 
     # -- readers -------------------------------------------------------------------------------------------
+    def load_checkpoint(self, experiment_dir: Path, model: torch.nn.Module, stem: str = "final",
+                        optimizer: Optional[torch.optim.Optimizer] = None) -> Dict[str, Any]:
+        """Weights from `checkpoints/{stem}.pt` (a reference checkpoint loads the same way) and, when the side file
+        exists, the dead counters and the optimizer state.  Returns the side file's dict ({} without one)."""
+        weights = Path(experiment_dir) / "checkpoints" / f"{stem}.pt"
+        dev = next(model.parameters()).device
+        model.load_state_dict(torch.load(weights, map_location=dev, weights_only=True))
+        side = weights.with_name(f"{stem}.extra.pt")
+        if not side.exists():
+            return {}
+        extra = torch.load(side, map_location=dev, weights_only=True)
+        if "num_batches_not_active" in extra and hasattr(model, "num_batches_not_active"):
+            model.num_batches_not_active = extra["num_batches_not_active"].to(dev)
+        if optimizer is not None and "optimizer" in extra:
+            optimizer.load_state_dict(extra["optimizer"])
+        return extra
+
     def list_experiments(self, model_name: Optional[str] = None, layer: Optional[int] = None) -> Dict[str, Any]:
         found: Dict[str, Any] = {}
         for mdir in sorted(p for p in self.base_dir.iterdir() if p.is_dir()):

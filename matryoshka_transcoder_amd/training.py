@@ -77,6 +77,11 @@ class FusedAdam(torch.optim.Optimizer):
         tc = self.transcoder
         if not tc.training:
             raise _lib.MtcError("train_step() needs the transcoder in training mode")
+        with tc._on_device(x_source):
+            return self._train_step(x_source, x_target)
+
+    def _train_step(self, x_source, x_target):
+        tc = self.transcoder
         tc._defer_dvals = True          # d a_bj comes out of the decoder-gradient kernel below
         if getattr(tc, "_side_stream", None) is None and getattr(tc, "_overlap_ok", True) and x_source.is_cuda:
             tc._side_stream = torch.cuda.Stream(device=x_source.device)
@@ -146,6 +151,10 @@ class FusedAdam(torch.optim.Optimizer):
     def step(self, closure=None, project: bool = False):
         if closure is not None:
             raise _lib.MtcError("FusedAdam does not take a closure")
+        with self.transcoder._on_device(None):
+            return self._step(project)
+
+    def _step(self, project: bool):
         tc = self.transcoder
         hp = tc.hot_path()
         for group in self.param_groups:
@@ -215,7 +224,7 @@ def train_transcoder(transcoder, activation_store, model, cfg):
                 if perf_now:
                     log_transcoder_performance(log, i, model, activation_store, transcoder)
                 if ckpt_now:
-                    results.save_checkpoint(exp_dir, transcoder, cfg, i, metrics_of(out), is_final=False)
+                    results.save_checkpoint(exp_dir, transcoder, cfg, i, metrics_of(out), is_final=False, optimizer=optimizer)
                 if sample_now:
                     collect_activation_samples(sample_collector, transcoder, activation_store)
                 out["loss"].backward()
@@ -233,7 +242,8 @@ def train_transcoder(transcoder, activation_store, model, cfg):
     final_cfg = dict(cfg)
     final_cfg["completed_steps"] = num_batches
     if out is not None:
-        results.save_checkpoint(exp_dir, transcoder, final_cfg, num_batches, metrics_of(out), is_final=True)
+        results.save_checkpoint(exp_dir, transcoder, final_cfg, num_batches, metrics_of(out), is_final=True,
+                                optimizer=optimizer)
     if sample_collector is not None:
         results.save_activation_samples(exp_dir, sample_collector, cfg.get("top_features_to_save", 100),
                                         cfg.get("samples_per_feature_to_save", 10))

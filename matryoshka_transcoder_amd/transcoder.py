@@ -13,6 +13,7 @@ gradient rows want; `state_dict()` round-trips with reference checkpoints unchan
 """
 from __future__ import annotations
 
+import contextlib
 import math
 from typing import Optional
 
@@ -34,7 +35,9 @@ class _StepFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, x_source, x_target, W_enc, b_enc, W_dec, b_dec):
         need_grad = any(ctx.needs_input_grad[3:])
-        res = module._run_forward(x_source, x_target, W_enc, b_enc, W_dec, b_dec, need_grad)
+        module._check_inputs(x_source, x_target)
+        with module._on_device():
+            res = module._run_forward(x_source, x_target, W_enc, b_enc, W_dec, b_dec, need_grad)
         ctx.module = module
         ctx.res = res
         module._last_res = res
@@ -49,7 +52,8 @@ class _StepFn(torch.autograd.Function):
         if res.g is None:
             raise _lib.MtcError("backward called on a forward that did not record gradients")
         module = ctx.module
-        dW_dec, dW_encT, db_enc, db_dec = module._run_backward(res, g_loss)
+        with module._on_device():
+            dW_dec, dW_encT, db_enc, db_dec = module._run_backward(res, g_loss)
         return None, None, None, dW_encT.t(), db_enc, dW_dec, db_dec
 
 
@@ -88,6 +92,7 @@ class MatryoshkaTranscoder(nn.Module):
         self.x_std = None
         self._hp: Optional[HotPath] = None
         self._last_res = None
+        self._side_inputs = None
         self._dead_check_in = 0          # forwards until a dead feature can exist (host-side bound)
         self.to(cfg["dtype"]).to(cfg["device"])
 
@@ -137,6 +142,27 @@ class MatryoshkaTranscoder(nn.Module):
                                 f"{x_source.device} input and there is no CPU fallback")
         if x_source.dtype != self.dtype or (x_target is not None and x_target.dtype != self.dtype):
             raise _lib.MtcError(f"inputs must have the model dtype {self.dtype}")
+        dev = self.W_dec.device
+        if x_source.device != dev or (x_target is not None and x_target.device != dev):
+            raise _lib.MtcError(f"inputs live on {x_source.device}"
+                                f"{'' if x_target is None else ' / ' + str(x_target.device)} but the parameters on {dev}: "
+                                "libmtc launches on one GPU and takes raw pointers, move the inputs first")
+
+    _NULL_CTX = contextlib.nullcontext()
+
+    def _on_device(self, x=None):
+        """Context that makes the parameters' GPU the current one (libmtc launches on HIP's current device and on
+        torch's current stream OF that device, whatever the caller's current device is -- the reference honours
+        cfg['device'] = 'cuda:1' without a set_device call because ATen ops carry device guards).  Free when the
+        device already is current."""
+        dev = self.W_dec.device
+        if dev.type != "cuda":
+            raise _lib.MtcError(f"the parameters live on {dev}: matryoshka_transcoder_amd computes on the GPU only")
+        if x is not None and x.device != dev:
+            raise _lib.MtcError(f"input on {x.device} but the parameters on {dev}")
+        if torch.cuda.current_device() == dev.index:
+            return self._NULL_CTX
+        return torch.cuda.device(dev)
 
     # ------------------------------------------------------------------ reference helper methods
     def preprocess_input(self, x):
@@ -146,7 +172,8 @@ class MatryoshkaTranscoder(nn.Module):
         self._check_inputs(x)
         hp = self.hot_path()
         x2 = x.reshape(-1, x.shape[-1]).contiguous()
-        xn, mean, std = hp.normalize(hp.desc(x2.shape[0]), x2)
+        with self._on_device():
+            xn, mean, std = hp.normalize(hp.desc(x2.shape[0]), x2)
         shp = x.shape[:-1] + (1,)
         return xn.reshape(x.shape), mean.reshape(shp), std.reshape(shp)
 
@@ -163,7 +190,8 @@ class MatryoshkaTranscoder(nn.Module):
             raise _lib.MtcError("W_dec.grad is None: call backward() first")
         if not self.W_dec.grad.is_contiguous():
             self.W_dec.grad = self.W_dec.grad.contiguous()
-        self.hot_path().unitnorm_project(self.W_dec.data, self.W_dec.grad)
+        with self._on_device():
+            self.hot_path().unitnorm_project(self.W_dec.data, self.W_dec.grad)
 
     @torch.no_grad()
     def update_inactive_features(self, acts):
@@ -265,8 +293,13 @@ class MatryoshkaTranscoder(nn.Module):
         x_hat, g, d_vals, row_stats, scalars, aux = self._decode_and_losses(
             hp, d, sel, acts, W_dec.contiguous(), b_dec.contiguous(), x_target, mean, std, need_grad, aux_active)
         from .engine import ForwardResult
-        return ForwardResult(B=B, desc=d, x_norm=xn, mean=mean, std=std, acts=None, sel=sel, x_hat=x_hat,
-                             g=g if need_grad else None, d_vals=d_vals, row_stats=row_stats, scalars=scalars, aux=aux)
+        res = ForwardResult(B=B, desc=d, x_norm=xn, mean=mean, std=std, acts=None, sel=sel, x_hat=x_hat,
+                            g=g if need_grad else None, d_vals=d_vals, row_stats=row_stats, scalars=scalars, aux=aux)
+        # main-pool temporaries a side-stream launch reads (the loss reduction): alive until the next step has joined
+        # the side stream, so the caching allocator cannot hand their blocks to a later main-stream allocation
+        res.extra["side_stream_inputs"] = self._side_inputs
+        self._side_inputs = None
+        return res
 
     def _decode_and_losses(self, hp, d, sel, acts, W_dec, b_dec, x_target, mean, std, need_grad, aux_active):
         """a6-a10: decode + losses (+ aux).  Overridden by the feature-sharded model."""
@@ -279,6 +312,7 @@ class MatryoshkaTranscoder(nn.Module):
             want_dvals=need_grad and not aux_active and not defer, l1_term=l1_term)
         aux = None
         aux_rows = None
+        self._side_inputs = None
         if aux_active:
             aux, aux_rows = self._run_aux(hp, d, acts, sel, W_dec, x_target, x_hat, g, need_grad, l1_term)
             # g now carries the aux contribution; the fused step (defer) derives d a_bj from it inside the decoder-
@@ -291,6 +325,7 @@ class MatryoshkaTranscoder(nn.Module):
             main, side = torch.cuda.current_stream(), self._side_stream
             e_rows = torch.cuda.Event()
             e_rows.record(main)
+            self._side_inputs = (row_stats, aux_rows, sel.state)
             with torch.cuda.stream(side):
                 side.wait_event(e_rows)
                 scalars = hp.reduce_scalars(d, row_stats, sel, self.total_dict_size, float(cfg["l1_coeff"]),
@@ -335,9 +370,10 @@ class MatryoshkaTranscoder(nn.Module):
         self._check_inputs(x_source)
         hp = self.hot_path()
         d = hp.desc(x_source.shape[0])
-        acts = hp.encode(d, x_source.contiguous(), self._w_encT(self.W_enc), self.b_enc)
-        sel = self._select(hp, d, acts, self.training)
-        return acts, hp.densify(d, sel, hp.D)
+        with self._on_device():
+            acts = hp.encode(d, x_source.contiguous(), self._w_encT(self.W_enc), self.b_enc)
+            sel = self._select(hp, d, acts, self.training)
+            return acts, hp.densify(d, sel, hp.D)
 
     def forward(self, x_source, x_target):
         """sae.py:195-269.  Returns the reference's dict; `loss` carries the autograd graph."""
@@ -383,13 +419,14 @@ class MatryoshkaTranscoder(nn.Module):
         hp = self.hot_path()
         d = hp.desc(x2.shape[0])
         max_col = self.prefix_indices[self.active_prefixes]
-        if not self.training and max_col == hp.D:
-            # eval mode: the threshold rides in the encoder's epilogue; the dense result is written once
-            result = hp.encode_threshold(d, x2, self._w_encT(self.W_enc), self.b_enc, self.threshold)
-        else:
-            acts = hp.encode(d, x2, self._w_encT(self.W_enc), self.b_enc)
-            sel = self._select(hp, d, acts, self.training)
-            result = hp.densify(d, sel, max_col)
+        with self._on_device():
+            if not self.training and max_col == hp.D:
+                # eval mode: the threshold rides in the encoder's epilogue; the dense result is written once
+                result = hp.encode_threshold(d, x2, self._w_encT(self.W_enc), self.b_enc, self.threshold)
+            else:
+                acts = hp.encode(d, x2, self._w_encT(self.W_enc), self.b_enc)
+                sel = self._select(hp, d, acts, self.training)
+                result = hp.densify(d, sel, max_col)
         if len(original_shape) == 3:
             result = result.reshape(original_shape[0], original_shape[1], -1)
         return result
@@ -397,15 +434,17 @@ class MatryoshkaTranscoder(nn.Module):
     def decode(self, acts_topk):
         """sae.py:389-406: reconstruction from a dense [N, D] feature tensor, de-normalised with the
         statistics remembered from the last encode()."""
-        if not hasattr(self, "x_mean"):
+        if self.x_mean is None and self.config.get("input_unit_norm", False):
+            # the reference raises AttributeError here too: its x_mean / x_std only exist after an encode() (sae.py:406)
             raise AttributeError("decode() needs the statistics of a previous encode()")
         self._check_inputs(acts_topk)
         hp = self.hot_path()
         max_idx = self.prefix_indices[self.active_prefixes]
-        if max_idx != hp.D:
-            sub = HotPath(self.source_act_size, self.target_act_size, [max_idx], self.dtype, False)
-            return self._decode_with(sub, acts_topk[:, :max_idx].contiguous(), self.W_dec[:max_idx])
-        return self._decode_with(hp, acts_topk.contiguous(), self.W_dec)
+        with self._on_device():
+            if max_idx != hp.D:
+                sub = HotPath(self.source_act_size, self.target_act_size, [max_idx], self.dtype, False)
+                return self._decode_with(sub, acts_topk[:, :max_idx].contiguous(), self.W_dec[:max_idx])
+            return self._decode_with(hp, acts_topk.contiguous(), self.W_dec)
 
     def _decode_with(self, hp, dense, W_dec):
         import ctypes as C

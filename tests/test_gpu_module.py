@@ -250,3 +250,68 @@ def test_two_stream_step_is_bit_identical(name, gpu_lib):
         assert torch.equal(pa, pb), n
         assert torch.equal(oa.state[pa]["exp_avg_sq"], ob.state[pb]["exp_avg_sq"]), n
     assert torch.equal(ma.num_batches_not_active, mb.num_batches_not_active)
+
+
+def test_device_guard_and_device_mismatch(gpu_lib, monkeypatch):
+    """libmtc launches on HIP's current device with raw pointers: every public entry point makes the parameters' GPU
+    current first (free when it already is) and refuses inputs that live elsewhere (a caller whose current
+    device differs from cfg['device'] would otherwise launch on the wrong GPU)."""
+    import contextlib
+    from matryoshka_transcoder_amd import _lib
+    fx, cfg = load_golden("fp32_plain")
+    m, _ = _model(fx, cfg)
+    assert isinstance(m._on_device(), contextlib.nullcontext)           # already current: no guard object, no cost
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 1)        # a caller sitting on another GPU
+    guard = m._on_device()
+    assert isinstance(guard, torch.cuda.device) and guard.idx == 0      # would switch to the parameters' GPU
+    monkeypatch.undo()
+    x = fx["steps"][0]["x_source"].to(DEV)
+
+    class Elsewhere:                                                    # a tensor-like on another GPU
+        device = torch.device("cuda:1"); is_cuda = True; dtype = x.dtype
+    with pytest.raises(_lib.MtcError, match="cuda:1"):
+        m._check_inputs(Elsewhere())
+    with pytest.raises(_lib.MtcError):
+        m._on_device(Elsewhere())
+    out = m(x, fx["steps"][0]["x_target"].to(DEV))                      # and the guarded path still computes
+    _close(out["l2_loss"], fx["steps"][0]["out"]["l2_loss"], 1e-4, 1e-6, "l2 through the guard")
+
+
+def test_checkpoint_resume_is_bit_identical(gpu_lib, tmp_path):
+    """results.py: the side file carries the optimizer state and the dead counters; a run resumed from
+    checkpoints/step_N.{pt,extra.pt} continues exactly like the uninterrupted one (the reference saves weights only)."""
+    from matryoshka_transcoder_amd.results import CleanResultsManager
+    from matryoshka_transcoder_amd.training import FusedAdam
+    fx, cfg = load_golden("bf16_unit")
+    steps = fx["steps"]
+
+    def fresh():
+        m, c = _model(fx, cfg)
+        return m, FusedAdam(m, lr=c["lr"], betas=(c["beta1"], c["beta2"]))
+
+    def run(m, opt, batches):
+        out = None
+        for s in batches:
+            out = opt.train_step(s["x_source"].to(DEV), s["x_target"].to(DEV))
+        return out
+
+    ma, oa = fresh()
+    run(ma, oa, steps[:2])
+    mgr = CleanResultsManager(str(tmp_path))
+    exp = mgr.create_experiment_dir("m", 0, 3)
+    mgr.save_checkpoint(exp, ma, dict(cfg), 2, {"loss": 0.0}, optimizer=oa)
+    out_a = run(ma, oa, steps[2:] + steps[:2])
+    mb, ob = fresh()
+    extra = mgr.load_checkpoint(exp, mb, "step_2", optimizer=ob)
+    assert extra["step"] == 2 and "optimizer" in extra
+    out_b = run(mb, ob, steps[2:] + steps[:2])
+    for k in out_a:
+        assert torch.equal(out_a[k], out_b[k]), k
+    for (n, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+        assert torch.equal(pa, pb), n
+        assert torch.equal(oa.state[pa]["exp_avg_sq"], ob.state[pb]["exp_avg_sq"]), n
+        assert oa.state[pa]["step"] == ob.state[pb]["step"]
+    assert torch.equal(ma.num_batches_not_active, mb.num_batches_not_active)
+    # the weights file alone is a reference-layout checkpoint
+    sd = torch.load(exp / "checkpoints" / "step_2.pt", weights_only=True)
+    assert list(sd.keys()) == ["b_enc", "W_enc", "W_dec", "b_dec", "threshold"] and sd["W_enc"].is_contiguous()

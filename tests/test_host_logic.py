@@ -1,6 +1,7 @@
 """CPU-only tests of the host-side mirror of the reference interface: config defaults / hook names,
 LR schedules, the activation store, and the reference import paths."""
 import math
+import os
 import sys
 
 import pytest
@@ -95,3 +96,26 @@ def test_reference_import_paths():
     from eval.sae_bench.config import NPZTranscoderSpec  # noqa: F401
     from matryoshka_transcoder_amd.transcoder import MatryoshkaTranscoder as B
     assert A is B and issubclass(MatryoshkaAutoInterpAdapter, B)
+
+
+def test_bench_launches_one_rank_per_gpu_by_itself():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment starts 2 ranks itself (it used to bench
+    one GPU silently); rank 0 alone prints the JSON line, with the world size the ranks saw.  CPU / gloo rehearsal."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["MTC_BENCH_LAUNCH_TEST"] = "1"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    rec = json.loads(lines[0])
+    assert rec == {"launch_test": True, "n_gpus": 2, "ranks_seen": 2}
+    # a world size that contradicts --gpus is refused instead of benchmarking something else
+    env2 = dict(env, WORLD_SIZE="4", RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env2, capture_output=True,
+                       text=True, timeout=120)
+    assert p.returncode == 2 and "WORLD_SIZE" in p.stderr
