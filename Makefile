@@ -2,7 +2,7 @@
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH  ?= gfx950
 CSRC  := matryoshka_transcoder_amd/csrc
-SRCS  := $(CSRC)/api.hip $(CSRC)/encode.hip $(CSRC)/select.hip $(CSRC)/decode.hip $(CSRC)/backward.hip $(CSRC)/optim.hip $(CSRC)/aux.hip $(CSRC)/collect.hip
+SRCS  := $(CSRC)/api.hip $(CSRC)/encode.hip $(CSRC)/select.hip $(CSRC)/decode.hip $(CSRC)/backward.hip $(CSRC)/optim.hip $(CSRC)/aux.hip $(CSRC)/collect.hip $(CSRC)/store.hip
 OBJS  := $(SRCS:.hip=.o)
 LIB   := matryoshka_transcoder_amd/libmtc.so
 FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -Wno-unused-result

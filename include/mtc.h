@@ -355,6 +355,16 @@ int mtc_aux_count_at(const mtc_desc* d, const void* acts, const int32_t* dead_id
 int mtc_densify(const mtc_desc* d, const int32_t* row_ptr, const int32_t* col_idx, const void* vals,
                 int32_t max_col, void* dense, void* stream);
 
+/* f1  activation-store batch assembly (transcoder_activation_store.py:184-207: DataLoader(TensorDataset(source,
+ * target), batch_size, shuffle=True) -> next_batch()).  ONE launch gathers rows perm[0..n_rows) of the source buffer
+ * [buffer_rows][A_s] and of the target buffer [buffer_rows][A_t] (model dtype, rows a multiple of 16 bytes) into
+ * out_source [n_rows][A_s] / out_target [n_rows][A_t]: pairs travel together.  perm: int64 device indices (one slice
+ * of a permutation of the buffer rows per batch).  An index outside [0, buffer_rows) is never dereferenced: that
+ * output row is zeroed and *bad_index_count (optional device int32, caller-zeroed) incremented. */
+int mtc_gather_row_pairs(int32_t dtype, int32_t n_rows, int32_t A_s, int32_t A_t, int64_t buffer_rows,
+                         const void* source_buffer, const void* target_buffer, const int64_t* perm,
+                         void* out_source, void* out_target, int32_t* bad_index_count, void* stream);
+
 /* SURVEY 8f row 4 -- top-activating-sample tables (replaces ActivationSampleCollector.collect_batch_samples /
  * _add_sample, src/utils/activation_samples.py:83-183, called from training.py:138-152).
  * Input: the CSC view (col_ptr[D+1], csc_row, csc_pos -> vals in the model dtype) of the sparse activations of

@@ -5,7 +5,10 @@ cfg["device"] in cfg["dtype"], `get_batch_tokens`, `get_paired_activations`, `ge
 
 What changed underneath: the reference wraps device tensors in a TensorDataset + DataLoader
 (shuffle=True), i.e. per-sample host indexing and a host-side collate of B device rows per batch.
-Here the buffer stays on the GPU and a batch is one `randperm` slice + one row gather.
+Here the buffer stays in HBM, the shuffle is one device `randperm` per refill and a batch is ONE libmtc
+launch (`mtc_gather_row_pairs`, csrc/store.hip) that gathers the source and target rows of a permutation
+slice together.  A CPU-resident store (cfg["device"] = "cpu": host-logic tests, data staging) keeps the
+same logic with a torch row gather; the GPU path has no such fallback.
 Three sources:
   * a language model exposing `run_with_cache(tokens, names_filter=..., stop_at_layer=...)` and a
     token iterator (the reference's path; needs transformer_lens + a dataset, neither ships here);
@@ -14,11 +17,15 @@ Three sources:
 """
 from __future__ import annotations
 
+import contextlib
 from typing import Iterator, Optional, Tuple
 
 import torch
 
 from .config import create_transcoder_config  # noqa: F401  (re-exported like the reference module)
+
+
+_NULL = contextlib.nullcontext()
 
 
 class SyntheticSource:
@@ -135,4 +142,24 @@ class TranscoderActivationsStore:
             self._cursor = 0
         idx = self._perm[self._cursor:self._cursor + B]      # last batch may be short, like the DataLoader's
         self._cursor += B
-        return self.source_buffer.index_select(0, idx), self.target_buffer.index_select(0, idx)
+        return self._gather_pairs(idx)
+
+    def _gather_pairs(self, idx: torch.Tensor):
+        src, tgt = self.source_buffer, self.target_buffer
+        if not src.is_cuda:
+            return src.index_select(0, idx), tgt.index_select(0, idx)
+        import ctypes as C
+        from . import _lib
+        from .engine import _p, _stream, dtype_code
+        if not (src.is_contiguous() and tgt.is_contiguous() and src.dtype == tgt.dtype and tgt.device == src.device):
+            raise _lib.MtcError("activation buffers must be contiguous, of one dtype, on one GPU")
+        n = idx.numel()
+        out_s = torch.empty(n, src.shape[1], dtype=src.dtype, device=src.device)
+        out_t = torch.empty(n, tgt.shape[1], dtype=tgt.dtype, device=tgt.device)
+        idx = idx.contiguous()
+        ctx = torch.cuda.device(src.device) if torch.cuda.current_device() != src.device.index else _NULL
+        with ctx:
+            _lib.check(_lib.load().mtc_gather_row_pairs(dtype_code(src.dtype), n, src.shape[1], tgt.shape[1], src.shape[0],
+                                                        _p(src), _p(tgt), _p(idx), _p(out_s), _p(out_t), None, _stream()),
+                       "mtc_gather_row_pairs")
+        return out_s, out_t
