@@ -290,7 +290,7 @@ def main():
             "backward": ("hbm", 2 * D * A * s + 2 * B * A * s + nnz * 12, 2 * nnz * A * s),
         }
         # stage -> (launches per step, kernel name in the committed PMC summary) for the stages priced below
-        launches = {"encode": (1, "mtc::encode_bf16_mfma256_kernel"), "decode": (1, "mtc::decode_fwd_kernel<1, 5>"),
+        launches = {"encode": (1, "mtc::encode_bf16_mfma256p_kernel<false>"), "decode": (1, "mtc::decode_fwd_kernel<1, 5>"),
                     "fused_backward_adam": (2, "mtc::fused_grad_adam_kernel<1, 1, 5, 1, 1, 0>")}
         kernels = {}
         for n, t_ms in st.items():
@@ -313,14 +313,18 @@ def main():
         # HBM-side bytes per launch of that kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE,
         # profiles/README.md); only valid for the workload / dtype they were taken on
         traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r01j_pmc_traffic.json")
-        if args.workload == "gemma2-2b" and args.dtype == "bf16" and not args.unit_norm and os.path.exists(pmc_path):
-            with open(pmc_path) as f:
+        import glob
+        pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r02*_pmc_traffic.json")))      # newest round-2 summary
+        traffic_src = None
+        if args.workload == "gemma2-2b" and args.dtype == "bf16" and not args.unit_norm and pmc_files:
+            with open(pmc_files[-1]) as f:
                 pmc = json.load(f)["kernels"]
             traffic = pmc.get(launches.get(dom, (None, ""))[1], {}).get("hbm_bytes_per_launch")
+            traffic_src = os.path.relpath(pmc_files[-1], ROOT)
         result["roofline"] = {"kernel": launches.get(dom, (None, dom))[1] or dom, "stage": dom,
                               **{k2: kernels[dom][k2] for k2 in ("bound", "achieved", "peak", "unit", "frac")},
-                              "launch_ms": per_launch(dom), "traffic": traffic, "traffic_unit": "bytes/launch"}
+                              "launch_ms": per_launch(dom), "traffic": traffic, "traffic_unit": "bytes/launch",
+                              "traffic_source": traffic_src}
         result["stages"] = kernels
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.workload, dtype)

@@ -36,4 +36,41 @@ json.dump(doc, open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1)
 shutil.copy(f"gpurun_out/prof_{tag}/{tag}_kernel_stats.csv", f"profiles/{tag}_kernel_stats.csv")
 shutil.copy(f"gpurun_out/bench_{tag}.json", f"profiles/{tag}_bench_line.json")
 shutil.copy("gpurun_out/sweep.json", f"profiles/{tag}_sweep.json")
+# encoder evidence (tools/measure.sh): PMC pass + kernel duration of the SAME short program -> clock held, MFMA-pipe busy
+import os
+if os.path.exists("gpurun_out/pmc_enc/e_counter_collection.csv"):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open("gpurun_out/pmc_enc/e_counter_collection.csv")):
+        agg[r["Kernel_Name"].split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    dur = {}
+    for r in csv.DictReader(open("gpurun_out/prof_enc/e_kernel_stats.csv")):
+        dur[r["Name"].split("(")[0].replace("void ", "")] = float(r["AverageNs"])
+    enc = {}
+    for k, c in agg.items():
+        if "encode" not in k:
+            continue
+        m = {n: sum(v) / len(v) for n, v in c.items()}
+        ns = dur.get(k)
+        e = {"counters_avg_per_launch": m, "launches": len(next(iter(c.values()))), "avg_ns_kernel_trace": ns}
+        if ns and "GRBM_GUI_ACTIVE" in m:
+            cyc = m["GRBM_GUI_ACTIVE"] / 8.0                      # rocprofv3 sums the 8 XCDs
+            e["cycles_per_xcd"] = cyc
+            e["clock_GHz"] = cyc / ns
+            e["mfma_pipe_busy_frac"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * cyc)     # 1024 SIMDs
+            e["mfma_bound_ms_at_held_clock"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / e["clock_GHz"] * 1e-6
+        if "SQ_WAVE_CYCLES" in m:
+            for n in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS"):
+                e[n + "_share_of_wave_cycles"] = m[n] / m["SQ_WAVE_CYCLES"]
+        enc[k] = e
+    extra = {}
+    for name in ("enc_random", "enc_zeros", "enc_stamps"):
+        try:
+            extra[name] = json.load(open(f"gpurun_out/{name}.json"))
+        except Exception:
+            pass
+    json.dump({"command": "rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY "
+                          "SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -- python3 tools/encode_only.py "
+                          "--reps 10 (config #2 operands, random data, back-to-back launches) and rocprofv3 --kernel-trace --stats "
+                          "of the same program for the duration",
+               "kernels": enc, "yardsticks": extra}, open(f"profiles/{tag}_encode_pmc.json", "w"), indent=1)
 print("profiles updated for", tag)
