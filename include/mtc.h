@@ -192,6 +192,9 @@ int mtc_decode_partial(const mtc_desc* d, const int32_t* row_ptr, const int32_t*
                        const void* vals, const void* W_dec, int32_t rows_per_shard,
                        float* partial_last, void* partial_pre,
                        float* abs_rows /* [B] sum |a| of the local entries, or NULL */, void* stream);
+/* mtc_decode_finish may be called in two parts so that the exchange of the earlier prefixes (FVU metrics only) can run
+ * beside the backward kernels: partial_pre = NULL finishes the last prefix only (x_hat, g, its SSE row, the target
+ * moments); partial_last = NULL (x_hat / g may be NULL) writes only the SSE rows of prefixes 0 .. G-2. */
 int mtc_decode_finish(const mtc_desc* d, int32_t B_total, const float* partial_last,
                       const void* partial_pre, const void* b_dec, const void* x_target,
                       const void* mean, const void* std, void* x_hat, void* g, float* row_stats,

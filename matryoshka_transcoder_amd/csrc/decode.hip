@@ -257,6 +257,7 @@ __global__ __launch_bounds__(256) void decode_finish_kernel(DecodeParams p, cons
     float sx = 0.f, sxx = 0.f;
     for (int gi = 0; gi < p.G; ++gi) {
         const bool last = gi == p.G - 1;
+        if (last ? partial_last == nullptr : partial_pre == nullptr) continue;     // split calls: last prefix now, the others later
         float sse = 0.f;
         for (int c = lane; c < nch; c += 64) {
             float a[8], b[8], t[8], r[8], gg[8];
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(256) void decode_finish_kernel(DecodeParams p, cons
         if (lane == 0) row_stats[(size_t)gi * p.B + row] = sse;
     }
     sx = wave_sum(sx); sxx = wave_sum(sxx);
-    if (lane == 0) {
+    if (lane == 0 && partial_last) {
         row_stats[(size_t)(p.G + 0) * p.B + row] = sx;
         row_stats[(size_t)(p.G + 1) * p.B + row] = sxx;
     }
@@ -401,7 +402,7 @@ extern "C" int mtc_decode_finish(const mtc_desc* d, int32_t B_total, const float
                                  const void* b_dec, const void* x_target, const void* mean, const void* std, void* x_hat,
                                  void* g, float* row_stats, void* recons, void* stream) {
     if (check_desc(d, "mtc_decode_finish")) return -1;
-    MTC_REQUIRE(partial_last && (partial_pre || d->G == 1) && b_dec && x_target && x_hat && row_stats,
+    MTC_REQUIRE((partial_last || partial_pre) && b_dec && x_target && row_stats && (x_hat || !partial_last),
                 "mtc_decode_finish: null pointer");
     MTC_REQUIRE(!d->unit_norm || (mean && std), "mtc_decode_finish: unit_norm needs mean/std");
     MTC_REQUIRE(B_total >= d->B, "mtc_decode_finish: B_total (%d) < local rows (%d)", B_total, d->B);

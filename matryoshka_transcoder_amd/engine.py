@@ -218,8 +218,8 @@ class HotPath:
         return d_vals
 
     def reduce_scalars(self, d, row_stats, sel: Selection, n_feat_total: int, l1_coeff: float, aux_penalty: float,
-                       aux_rows=None, nnz_abs_override=None):
-        scalars = torch.empty(16, dtype=torch.float32, device=row_stats.device)
+                       aux_rows=None, nnz_abs_override=None, out=None):
+        scalars = out if out is not None else torch.empty(16, dtype=torch.float32, device=row_stats.device)
         check(self.lib.mtc_reduce_scalars(C.byref(d), _p(row_stats), _p(aux_rows), _p(sel.state), _p(nnz_abs_override),
                                           int(n_feat_total), float(l1_coeff), float(aux_penalty), _p(scalars), _stream()),
               "mtc_reduce_scalars")

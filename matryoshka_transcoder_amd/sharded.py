@@ -120,6 +120,24 @@ class _Comm:
         dist.reduce_scatter_tensor(out, t.contiguous(), group=self.group)
         return out
 
+    def reduce_scatter_begin(self, t: torch.Tensor):
+        """reduce_scatter that runs beside whatever the caller enqueues next (RCCL: on the process group's own stream);
+        reduce_scatter_end() makes the current stream wait for it and returns this rank's block."""
+        if self.staged:
+            return (None, self.reduce_scatter(t), None)
+        n = t.shape[0] // self.world
+        t = t.contiguous()
+        out = torch.empty((n,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        work = dist.reduce_scatter_tensor(out, t, group=self.group, async_op=True)
+        return (work, out, t)                                  # operands stay referenced until the wait
+
+    @staticmethod
+    def reduce_scatter_end(handle) -> torch.Tensor:
+        work, out, _ = handle
+        if work is not None:
+            work.wait()                                        # stream-level wait: the host does not block
+        return out
+
     def all_gather(self, t: torch.Tensor) -> torch.Tensor:
         if self.staged and t.is_cuda:
             h = t.cpu()
@@ -370,11 +388,14 @@ class ShardedMatryoshkaTranscoder(MatryoshkaTranscoder):
         abs_rows = torch.empty(B, dtype=torch.float32, device=dev)
         check(lib.mtc_decode_partial(C.byref(d), _p(sel.row_ptr), _p(sel.col_idx), _p(sel.vals), _p(W_dec), rps,
                                      _p(p_last), _p(p_pre), _p(abs_rows), s), "mtc_decode_partial")
-        # reduce-scatter by batch rows: every rank finishes 1/W of the rows for all G prefixes
+        # reduce-scatter by batch rows: every rank finishes 1/W of the rows.  Only the LAST prefix is on the critical path
+        # (x_hat, g -> backward); the earlier prefixes feed FVU metrics only (sae.py:248-252), so inside the fused step
+        # their exchange is issued after the all-gather of g and runs beside the shard-local backward kernels
         my_last = self.comm.reduce_scatter(p_last)                         # [rps, A_t] fp32
-        my_pre = self.comm.reduce_scatter(p_pre)[0] if G > 1 else None      # [G-1, rps, A_t]
         dl = _lib.make_desc(rps, hp.A_s, hp.A_t, hp.D, hp.prefix, hp.code, hp.unit_norm)
         lo, hi = rank * rps, (rank + 1) * rps
+        mean_l = mean[lo:hi] if mean is not None else None
+        std_l = std[lo:hi] if std is not None else None
         # one byte buffer per rank = {x_hat, g of its rows | per-row statistics | nnz, sum|a| of its shard}: ONE all-gather
         # hands every rank all of g (its features fire on any row), the full reconstruction and the loss inputs
         es = x_target.element_size()
@@ -385,10 +406,8 @@ class ShardedMatryoshkaTranscoder(MatryoshkaTranscoder):
         nnz_abs_l = pack[n_xg + n_st:].view(torch.float32)
         stats_l.zero_()
         check(lib.mtc_shard_nnz_abs(C.byref(d), _p(abs_rows), _p(sel.state), _p(nnz_abs_l), s), "mtc_shard_nnz_abs")
-        check(lib.mtc_decode_finish(C.byref(dl), B, _p(my_last), _p(my_pre), _p(b_dec), _p(x_target[lo:hi]),
-                                    _p(mean[lo:hi] if mean is not None else None),
-                                    _p(std[lo:hi] if std is not None else None), _p(both_l[0]), _p(both_l[1]), _p(stats_l), None, s),
-              "mtc_decode_finish")
+        check(lib.mtc_decode_finish(C.byref(dl), B, _p(my_last), None, _p(b_dec), _p(x_target[lo:hi]), _p(mean_l), _p(std_l),
+                                    _p(both_l[0]), _p(both_l[1]), _p(stats_l), None, s), "mtc_decode_finish")
         allp = self.comm.all_gather(pack)                                   # [W, bytes]
         both = allp[:, :n_xg].view(self.dtype).view(W, 2, rps, A_t)
         x_hat = both[:, 0].reshape(B, A_t)
@@ -397,14 +416,34 @@ class ShardedMatryoshkaTranscoder(MatryoshkaTranscoder):
         nnz_abs = allp[:, n_xg + n_st:].view(torch.float32).sum(0).contiguous()
         l1_term = float(cfg["l1_coeff"]) / (B * self.total_dict_size)
         x_hat = x_hat.contiguous()
+        pre_handle = self.comm.reduce_scatter_begin(p_pre) if G > 1 else None
         aux, aux_rows = None, None
         if aux_active:
             aux, aux_rows = self._run_aux(hp, d, acts, sel, W_dec, x_target, x_hat, g, need_grad, l1_term)
         # the fused step derives d a_bj inside the decoder-gradient kernel, also with the dense aux branch active
         defer = getattr(self, "_defer_dvals", False) and (aux is None or bool(aux.get("dense")))
         d_vals = hp.decode_bwd_vals(d, sel, W_dec, g, l1_term) if need_grad and not defer else None
-        scalars = hp.reduce_scalars(d, row_stats, sel, self.total_dict_size, float(cfg["l1_coeff"]),
-                                    float(cfg["aux_penalty"]), aux_rows=aux_rows, nnz_abs_override=nnz_abs)
+        scalars = torch.empty(16, dtype=torch.float32, device=dev)
+        deferred = bool(getattr(self, "_defer_dvals", False))
+        # the deferred part runs after the optimizer kernels: it must see THIS step's b_dec (a few KB), not the updated one
+        b_dec_fwd = b_dec.clone() if deferred and pre_handle is not None else b_dec
+
+        def finish_metrics():
+            # SSE of prefixes 0 .. G-2 on this rank's rows, gathered into the per-row statistics; then the scalars
+            if pre_handle is not None:
+                my_pre = self.comm.reduce_scatter_end(pre_handle)[0]        # [G-1, rps, A_t]
+                sse_pre = torch.zeros(G + 4, rps, dtype=torch.float32, device=dev)
+                check(lib.mtc_decode_finish(C.byref(dl), B, None, _p(my_pre), _p(b_dec_fwd), _p(x_target[lo:hi]), _p(mean_l),
+                                            _p(std_l), None, None, _p(sse_pre), None, _stream()), "mtc_decode_finish")
+                allq = self.comm.all_gather(sse_pre[:G - 1].contiguous())   # [W, G-1, rps]
+                row_stats[:G - 1] = allq.permute(1, 0, 2).reshape(G - 1, B)
+            hp.reduce_scalars(d, row_stats, sel, self.total_dict_size, float(cfg["l1_coeff"]), float(cfg["aux_penalty"]),
+                              aux_rows=aux_rows, nnz_abs_override=nnz_abs, out=scalars)
+
+        if deferred:
+            self._deferred = finish_metrics          # FusedAdam.train_step: after the backward kernels are issued
+        else:
+            finish_metrics()
         return x_hat, g, d_vals, row_stats, scalars, aux
 
     # ------------------------------------------------------------------ checkpoints in the reference layout

@@ -145,7 +145,7 @@ class FusedAdam(torch.optim.Optimizer):
             torch.cuda.current_stream().wait_event(e_b)     # every later reader of b_dec / g / the scalars is ordered behind the side stream
         else:
             update_b_dec()
-        return tc._output_dict(res, x_target)
+        return tc._output_dict(res, x_target)               # (flushes what the forward chain deferred behind the backward launches)
 
     @torch.no_grad()
     def step(self, closure=None, project: bool = False):

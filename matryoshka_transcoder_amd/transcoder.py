@@ -93,6 +93,7 @@ class MatryoshkaTranscoder(nn.Module):
         self._hp: Optional[HotPath] = None
         self._last_res = None
         self._side_inputs = None
+        self._deferred = None
         self._dead_check_in = 0          # forwards until a dead feature can exist (host-side bound)
         self.to(cfg["dtype"]).to(cfg["device"])
 
@@ -380,8 +381,17 @@ class MatryoshkaTranscoder(nn.Module):
         loss, x_hat, s = _StepFn.apply(self, x_source, x_target, self.W_enc, self.b_enc, self.W_dec, self.b_dec)
         return self._output_dict(self._last_res, x_target, loss=loss)
 
+    def _flush_deferred(self):
+        """Work a forward chain postponed until the backward kernels were issued (the sharded model's exchange of the
+        earlier prefixes' reconstructions: metrics only, kept off the critical path).  No-op otherwise."""
+        fn = self._deferred
+        if fn is not None:
+            self._deferred = None
+            fn()
+
     def _output_dict(self, res, x_target, loss=None):
         """The reference's 11 keys with its dtypes (sae.py:257-269), from the device-resident scalars."""
+        self._flush_deferred()
         s, dt = res.scalars, self.dtype
         # the kernel already rounded l2 / l1 / l1_norm / loss to the model dtype (mtc_reduce_scalars), so ONE conversion of
         # the 16-float vector yields all of them exactly (a no-op for fp32 models); the entries are views of it

@@ -2,9 +2,14 @@
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
-timeout -k 10 300 python -u -m pytest tests/test_gpu_widths.py -m gpu -x -q --timeout 120 --timeout-method thread -p no:cacheprovider -k "256 or config2 or chain" > gpurun_out/t.log 2>&1 || { tail -30 gpurun_out/t.log; exit 1; }
-tail -1 gpurun_out/t.log
-for T in 3 2; do
-  timeout -k 10 120 python -u tools/encode_only.py --tile $T --reps 40 || exit 1
-done
-timeout -k 10 120 python -u tools/encode_only.py --tile 2 --zeros || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_sh -o sh -- python3 bench.py --sharded --no-cpu-baseline --steps 30 --warmup 5 > gpurun_out/prof_sh.json 2> gpurun_out/prof_sh.err || { tail -5 gpurun_out/prof_sh.err; exit 1; }
+python3 - <<'PY'
+import csv
+rows=list(csv.DictReader(open('gpurun_out/prof_sh/sh_kernel_stats.csv')))
+tot=0
+for r in rows[:40]:
+    n=int(r['Calls']); 
+    print(f"{r['Name'][:90]:90s} calls/step {n/35:5.1f} avg {float(r['AverageNs'])/1e3:8.1f} us  per-step {float(r['TotalDurationNs'])/35/1e3:8.1f}")
+    tot+=float(r['TotalDurationNs'])/35/1e3
+print('sum per step us', tot, 'launches per step', sum(int(r['Calls']) for r in rows)/35)
+PY
