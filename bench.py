@@ -117,7 +117,8 @@ def stage_times(tc, opt, pool, reps=5):
         setattr(hp, name, inner)
 
     for n in ("normalize", "encode", "select_topk", "threshold_ema", "build_csc", "decode", "decode_bwd_vals", "reduce_scalars",
-              "backward", "fused_backward_adam", "colsum", "unitnorm_adam", "adam_flat"):
+              "backward", "fused_backward_adam", "colsum", "unitnorm_adam", "adam_flat", "aux_dead_list", "aux_forward_dense",
+              "aux_extra_rows"):
         wrap(n)
     acc = {}
     for r in range(reps):
@@ -174,6 +175,9 @@ def main():
     ap.add_argument("--unit-norm", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sharded", action="store_true", help="use the feature-sharded classes even on one GPU (overhead check)")
+    ap.add_argument("--aux-active", action="store_true",
+                    help="SURVEY 8d: the step with the auxiliary dead-feature loss active (every 7th feature forced dead: "
+                         "tiny encoder column, counter preset); adds an `aux` block (its GEMMs on mtc_gemm_nt) to the line")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -232,6 +236,20 @@ def main():
         from matryoshka_transcoder_amd.training import FusedAdam
         tc = MatryoshkaTranscoder(cfg)
         opt = FusedAdam(tc, lr=cfg["lr"], betas=(cfg["beta1"], cfg["beta2"]))
+    n_forced = 0
+
+    def force_dead():
+        Dl = tc.hot_path().D                               # the local dictionary of a shard
+        forced = torch.arange(5, Dl, 7, device=device)
+        with torch.no_grad():
+            tc.W_enc[:, forced] *= 0.01                    # does not win the global TopK until the aux loss has revived it
+        cnt = tc.num_batches_not_active
+        cnt[forced] = float(cfg["n_batches_to_dead"])
+        tc.num_batches_not_active = cnt
+        return int(forced.numel())
+
+    if args.aux_active:
+        n_forced = force_dead()
     pool = batch_pool(B, A, dtype, device)
 
     def step(i):
@@ -248,11 +266,13 @@ def main():
     for i in range(args.warmup):
         step(i)
     fence()
+    n_dead_start = int((tc._cnt >= cfg["n_batches_to_dead"]).sum()) if args.aux_active else 0
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = step(i)
     fence()
     elapsed = time.perf_counter() - t0
+    n_dead_end = int((tc._cnt >= cfg["n_batches_to_dead"]).sum()) if args.aux_active else 0
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -268,14 +288,17 @@ def main():
         "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{args.workload}: act {A}, dict {D}, cumulative prefixes {cfg['prefix_sizes']}, "
-                               f"top_k {k}, batch {B}, input_unit_norm {args.unit_norm}",
+                               f"top_k {k}, batch {B}, input_unit_norm {args.unit_norm}"
+                               + (f", auxiliary loss ACTIVE ({n_forced} features forced dead)" if args.aux_active else ""),
                    "global_batch": B, "parallelism": "single GPU" if world == 1 else f"dictionary sharded x{world}",
                    "collective_world": world if (world > 1 or args.sharded) else None,
                    "collective_backend": collective_backend,
                    "final_loss": float(out["loss"].detach().float()), "final_l0": float(out["l0_norm"].detach())},
     }
     if rank == 0 and world == 1 and not args.sharded:
-        st = stage_times(tc, opt, pool)
+        if args.aux_active:
+            force_dead()          # the timed steps revived most of the dead set: per-stage times are taken on a full one again
+        st = stage_times(tc, opt, pool, reps=2 if args.aux_active else 5)
         s = 2 if dtype == torch.bfloat16 else 4
         nnz = k * B
         flop_enc = 2.0 * B * A * D
@@ -326,6 +349,21 @@ def main():
                               "launch_ms": per_launch(dom), "traffic": traffic, "traffic_unit": "bytes/launch",
                               "traffic_source": traffic_src}
         result["stages"] = kernels
+        if args.aux_active:
+            # the branch's four products over the dead set (sae.py:336-341 and its autograd), all on mtc_gemm_nt:
+            # forward B x A_t x n_pad, backward 3 products of the same volume; priced against the dense bf16 MFMA peak
+            n_dead = int((tc._cnt >= cfg["n_batches_to_dead"]).sum())      # after the per-stage passes (the branch revives features)
+            n_pad = tc.hot_path()._aux_bucket(n_dead, D)
+            t_aux = (st.get("aux_forward_dense", 0.0) + st.get("aux_extra_rows", 0.0)) * 1e-3
+            flop = 4 * 2.0 * B * n_pad * A
+            peak = MFMA_BF16_PEAK_TF if dtype == torch.bfloat16 else MFMA_F32_PEAK_TF
+            result["aux"] = {"forced_dead": n_forced, "n_dead_at_start_of_timed_steps": n_dead_start,
+                             "n_dead_at_end_of_timed_steps": n_dead_end, "n_dead": n_dead, "n_pad": n_pad, "aux_loss": float(out["aux_loss"].float()),
+                             "stage_ms": {k2: st.get(k2) for k2 in ("aux_dead_list", "aux_forward_dense", "aux_extra_rows")},
+                             "roofline": {"bound": "mfma", "achieved": flop / max(t_aux, 1e-9) / 1e12, "peak": peak,
+                                          "unit": "TFLOP/s", "frac": flop / max(t_aux, 1e-9) / 1e12 / peak,
+                                          "note": "4 products of 2*B*n_pad*A FLOP each over the select / fill / transpose / "
+                                                  "residual / mask launches of the branch as well (whole-branch time)"}}
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.workload, dtype)
     if rank == 0:

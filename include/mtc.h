@@ -313,8 +313,34 @@ int mtc_unitnorm_project(const mtc_desc* d, void* W_dec, void* grad, void* strea
  *                       aux_rows[b] = sum e^2; g_aux = 2 aux_penalty/(B A_t) e; g += g_aux*std_row
  *                       (residual not detached); d_aux_vals = g_aux . W_dec[j]
  * The aux gradients then reuse mtc_build_csc + mtc_backward_sparse(accumulate = 1). */
-int mtc_aux_dead_list(const mtc_desc* d, const float* cnt, float n_batches_to_dead, int32_t* dead_idx,
-                      int32_t* n_dead_dev, void* stream);
+int mtc_aux_dead_list(const mtc_desc* d, const float* cnt, float n_batches_to_dead, int32_t* dead_idx /* [D]; the tail
+                      beyond the count is filled with feature 0 (valid to gather through) */,
+                      int32_t* n_dead_dev, int32_t* row_map /* optional [D]: slot of the feature in dead_idx, or -1 */,
+                      int32_t* next_bound_dev /* optional: #features with cnt >= n_batches_to_dead - 1, an upper bound of
+                      the NEXT forward's count (a counter grows by at most 1 per forward): lets the caller size the next
+                      step's launches without waiting for that step's own count */,
+                      void* stream);
+
+/* a9 in the reference's own dense form over the compacted dead set (sae.py:336-341: acts_aux @ W_dec[dead], and the
+ * three products of its autograd), on the encoder's MFMA tiles -- no BLAS library on the path:
+ *   mtc_gemm_nt          C[m][n] = sum_k A[row(m)][k] Bt[n][k]; fp32 accumulation, ONE rounding to the model dtype
+ *                        (out_f32 = 0) or fp32 output (partial sums all-reduced over shards); row strides lda / ldb /
+ *                        ldc in elements; a_rows (optional) gathers A's rows (row(m) = a_rows[m]).  MFMA tiles when
+ *                        K % 64 == 0 (bf16; fp32: K % 32 == 0), N % 4 == 0 and 16-byte-aligned rows, else an FMA kernel.
+ *   mtc_transpose_rows   dst[c][r] = src[row(r)][c], r < R, c < C; dst columns R <= r < R_pad zero-filled (k-tile padding)
+ *   mtc_aux_mask_rowsum  d[j][b] = 0 where acts_auxT[j][b] <= 0 (TopK / ReLU mask), e_b[j] = sum_b d[j][b]
+ *   mtc_rows_scatter_add dst[idx[j]][:] = round(dst[idx[j]][:] + src[j][:]) (unique idx), the dense `grad[dead] += rows`
+ * Launch sizes may come from an upper bound of n_dead (mtc_aux_dead_list's next_bound): the list's tail is gatherable,
+ * padded columns of acts_aux are zero, and mtc_aux_residual / mtc_rows_scatter_add take the true count from the device. */
+int mtc_gemm_nt(int32_t dtype, int32_t M, int32_t N, int32_t K, const void* A, int64_t lda, const int32_t* a_rows,
+                const void* Bt, int64_t ldb, void* C, int64_t ldc, int32_t out_f32, void* stream);
+int mtc_transpose_rows(int32_t dtype, int32_t R, int32_t C, int32_t R_pad, const void* src, int64_t ld_src,
+                       const int32_t* src_rows, void* dst, int64_t ld_dst, void* stream);
+int mtc_aux_mask_rowsum(int32_t dtype, int32_t n, int32_t B, const void* acts_auxT, int64_t ld_a, void* d_actsT,
+                        int64_t ld_d, void* e_b, void* stream);
+int mtc_rows_scatter_add(int32_t dtype, int32_t n, int32_t A, const int32_t* idx, const void* src, int64_t ld_src,
+                         void* dst, int64_t ld_dst, int32_t dst_rows /* an idx outside [0, dst_rows) is skipped */,
+                         const int32_t* n_dev /* optional: only rows j < *n_dev */, void* stream);
 int mtc_aux_select(const mtc_desc* d, const void* acts, const int32_t* dead_idx,
                    const int32_t* n_dead_dev, int32_t top_k_aux, uint32_t* row_cnt,
                    uint32_t* row_tau_bits, uint32_t* row_tie_quota, void* stream);
@@ -340,7 +366,10 @@ int mtc_aux_dense_fill(const mtc_desc* d, const void* acts, const int32_t* dead_
                        const uint32_t* row_tau_bits, const uint32_t* row_tie_quota, int32_t n_pad, void* acts_aux,
                        void* stream);
 int mtc_aux_residual(const mtc_desc* d, const void* x_hat_aux, const void* x_target, const void* x_hat, const void* std,
-                     float aux_penalty, void* g, void* g_aux, float* aux_rows, void* stream);
+                     float aux_penalty, void* g, void* g_aux, float* aux_rows,
+                     const int32_t* active_dev /* optional device int32: 0 = no dead feature after all (sae.py:331): aux_rows
+                     and g_aux are zeroed and g is left alone */,
+                     void* stream);
 int mtc_aux_mask(int32_t dtype, uint64_t n, const void* acts_aux, void* d_acts_aux, void* stream);
 
 /* a9 over a feature-sharded dictionary ("per-row top-k_aux merge").  Each rank runs mtc_aux_select on its

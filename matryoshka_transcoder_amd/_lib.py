@@ -75,12 +75,16 @@ PROTOTYPES = {
     "mtc_fused_backward_adam_dec_extra": (C.c_int, [DP, P, P, P, P, P, P, P, P, P, HP, P, C.c_float, P, P, P]),
     "mtc_fused_backward_adam_enc_extra": (C.c_int, [DP, P, P, P, P, P, P, P, P, P, P, P, P, HP, P, P, P, P]),
     "mtc_unitnorm_project": (C.c_int, [DP, P, P, P]),
-    "mtc_aux_dead_list": (C.c_int, [DP, P, C.c_float, P, P, P]),
+    "mtc_aux_dead_list": (C.c_int, [DP, P, C.c_float, P, P, P, P, P]),
+    "mtc_gemm_nt": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, P, C.c_int64, P, P, C.c_int64, P, C.c_int64, C.c_int32, P]),
+    "mtc_transpose_rows": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, P, C.c_int64, P, P, C.c_int64, P]),
+    "mtc_aux_mask_rowsum": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, P, C.c_int64, P, C.c_int64, P, P]),
+    "mtc_rows_scatter_add": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, P, P, C.c_int64, P, C.c_int64, C.c_int32, P, P]),
     "mtc_aux_select": (C.c_int, [DP, P, P, P, C.c_int32, P, P, P, P]),
     "mtc_aux_fill": (C.c_int, [DP, P, P, P, P, P, P, P, P, P]),
     "mtc_aux_fwd": (C.c_int, [DP, P, P, P, P, P, P, P, C.c_float, P, P, P, P, P]),
     "mtc_aux_dense_fill": (C.c_int, [DP, P, P, P, P, P, C.c_int32, P, P]),
-    "mtc_aux_residual": (C.c_int, [DP, P, P, P, P, C.c_float, P, P, P, P]),
+    "mtc_aux_residual": (C.c_int, [DP, P, P, P, P, C.c_float, P, P, P, P, P]),
     "mtc_aux_mask": (C.c_int, [C.c_int32, C.c_uint64, P, P, P]),
     "mtc_aux_row_candidates": (C.c_int, [DP, P, P, P, P, P, C.c_int32, P, P]),
     "mtc_aux_count_at": (C.c_int, [DP, P, P, P, P, P, P, P]),

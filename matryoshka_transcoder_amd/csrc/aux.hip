@@ -14,24 +14,63 @@
 namespace mtc {
 
 // ---------------------------------------------------------------- dead list (one workgroup)
+// Chunks of 1024 consecutive features (coalesced counter reads); pass 1 leaves one count per (chunk, wave) in LDS, wave 0
+// turns them into exclusive offsets, pass 2 re-reads the counters (L2) and writes the ordered list, the feature -> slot
+// map and the gatherable tail.
 __global__ __launch_bounds__(1024) void dead_list_kernel(int D, const float* __restrict__ cnt, float n_to_dead,
-                                                         int32_t* __restrict__ dead_idx, int32_t* __restrict__ n_dead) {
-    __shared__ uint32_t sm[16];
+                                                         int32_t* __restrict__ dead_idx, int32_t* __restrict__ n_dead,
+                                                         int32_t* __restrict__ row_map /* optional [D]: slot in the list or -1 */,
+                                                         int32_t* __restrict__ next_bound /* optional: #features with cnt >= n_to_dead - 1 */) {
+    extern __shared__ uint32_t wc[];             // [chunks * 16]
+    __shared__ uint32_t sm_near[16];
+    __shared__ uint32_t s_total;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const int per = (D + 1023) / 1024;
-    const int j0 = t * per, j1 = min(D, j0 + per);
-    uint32_t mine = 0;
-    for (int j = j0; j < j1; ++j) mine += cnt[j] >= n_to_dead ? 1u : 0u;
-    uint32_t inc = mine;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const uint32_t n = __shfl_up(inc, o, 64); if (lane >= o) inc += n; }
-    if (lane == 63) sm[w] = inc;
+    const int chunks = (D + 1023) / 1024;
+    uint32_t near = 0;
+    for (int c = 0; c < chunks; ++c) {
+        const int j = c * 1024 + t;
+        const float v = j < D ? cnt[j] : -1.f;
+        near += v >= n_to_dead - 1.f ? 1u : 0u;  // a counter grows by at most 1 per forward: the next list's length bound
+        const uint64_t b = __ballot(v >= n_to_dead);
+        if (lane == 0) wc[c * 16 + w] = (uint32_t)__popcll(b);
+    }
+    near = wave_sum_u32(near);
+    if (lane == 0) sm_near[w] = near;
     __syncthreads();
-    uint32_t base = inc - mine, total = 0;
-    for (int i = 0; i < 16; ++i) { if (i < w) base += sm[i]; total += sm[i]; }
-    for (int j = j0; j < j1; ++j)
-        if (cnt[j] >= n_to_dead) dead_idx[base++] = j;
-    if (t == 0) *n_dead = (int32_t)total;
+    if (w == 0) {
+        uint32_t running = 0;
+        const int n = chunks * 16;
+        for (int base = 0; base < n; base += 64) {
+            const uint32_t v = base + lane < n ? wc[base + lane] : 0u;
+            uint32_t inc = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
+            if (base + lane < n) wc[base + lane] = running + inc - v;
+            running += __shfl(inc, 63, 64);
+        }
+        if (lane == 0) s_total = running;
+    }
+    __syncthreads();
+    const uint32_t total = s_total;
+    for (int c = 0; c < chunks; ++c) {
+        const int j = c * 1024 + t;
+        const bool dead = j < D && cnt[j] >= n_to_dead;
+        const uint64_t b = __ballot(dead);
+        const uint32_t pos = wc[c * 16 + w] + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+        if (j < D) {
+            if (row_map) row_map[j] = dead ? (int32_t)pos : -1;
+            if (dead) dead_idx[pos] = j;
+        }
+    }
+    // the tail of the list holds a valid feature (0): callers that size their launches from an upper bound of the
+    // count gather rows through it (those rows only ever meet zero activations / masked gradients)
+    for (int i = (int)total + t; i < D; i += 1024) dead_idx[i] = 0;
+    if (t == 0) {
+        uint32_t near_total = 0;
+        for (int i = 0; i < 16; ++i) near_total += sm_near[i];
+        *n_dead = (int32_t)total;
+        if (next_bound) *next_bound = (int32_t)near_total;
+    }
 }
 
 // ---------------------------------------------------------------- per-row top-k over the dead columns
@@ -151,7 +190,8 @@ __global__ __launch_bounds__(256) void aux_fwd_kernel(int B, int A_t, int unit_n
                                                       const void* __restrict__ std_p, void* __restrict__ g,
                                                       void* __restrict__ g_aux, float* __restrict__ aux_rows,
                                                       float* __restrict__ d_aux_vals,
-                                                      const void* __restrict__ x_hat_aux /* optional: reconstruction made elsewhere (dense GEMM path); then no gather */) {
+                                                      const void* __restrict__ x_hat_aux /* optional: reconstruction made elsewhere (dense GEMM path); then no gather */,
+                                                      const int32_t* __restrict__ active /* optional: *active == 0 -> the branch is off (sae.py:331) */) {
     typedef DType<DT> D_;
     typedef typename D_::T T;
     RowCtx<DT, NC> rc;
@@ -159,6 +199,16 @@ __global__ __launch_bounds__(256) void aux_fwd_kernel(int B, int A_t, int unit_n
     rc.nch = A_t >> 3;
     const int row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (row >= B) return;
+    if (active && *active == 0) {                 // no dead feature after all: zero loss, g untouched, zero g_aux
+        if (rc.lane == 0) aux_rows[row] = 0.f;
+        if (g_aux) {
+            const float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                if (rc.valid(c)) store8<DT>(g_aux, (size_t)row * A_t + rc.off(c), z);
+        }
+        return;
+    }
     const int e_begin = x_hat_aux ? 0 : row_ptr[row], e_end = x_hat_aux ? 0 : row_ptr[row + 1];
     float acc[NC][8];
 #pragma unroll
@@ -320,16 +370,126 @@ __global__ __launch_bounds__(256) void aux_mask_kernel(size_t n, const void* __r
         if (DType<DT>::ld(a + i) <= 0.f) dv[i] = (T)0;
 }
 
+// dst[c][r] = src[row(r)][c] for r < R, c < C (row(r) = src_rows[r] when given: gather + transpose in one pass);
+// columns R <= r < R_pad of dst are zero-filled (GEMM operands padded to the k-tile).  64 x 64 tiles through LDS.
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_rows_kernel(int R, int C, int R_pad, const T* __restrict__ src, long long ld_src,
+                                                             const int32_t* __restrict__ src_rows, T* __restrict__ dst,
+                                                             long long ld_dst) {
+    __shared__ T tile[64][65];
+    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        T v = (T)0;
+        if (r < R && c < C) {
+            const long long rr = src_rows ? (long long)src_rows[r] : (long long)r;
+            v = src[(size_t)rr * ld_src + c];
+        }
+        tile[i][tx] = v;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < C && r < R_pad) dst[(size_t)c * ld_dst + r] = tile[tx][i];
+    }
+}
+
+// Backward mask of the aux branch on the transposed layout: d[j][b] = 0 where the aux activation a[j][b] was not
+// selected (ReLU / TopK mask), and e_b[j] = sum_b d[j][b] (the encoder-bias gradient element of dead feature j), rounded
+// once to the model dtype.  One wave per dead feature.
+template <int DT>
+__global__ __launch_bounds__(256) void aux_mask_rowsum_kernel(int n, int B, const void* __restrict__ a_, long long ld_a,
+                                                              void* __restrict__ d_, long long ld_d, void* __restrict__ e_b) {
+    typedef DType<DT> D_;
+    typedef typename D_::T T;
+    const int lane = threadIdx.x & 63;
+    const int j = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (j >= n) return;
+    const T* a = reinterpret_cast<const T*>(a_) + (size_t)j * ld_a;
+    T* d = reinterpret_cast<T*>(d_) + (size_t)j * ld_d;
+    float s = 0.f;
+    for (int b = lane; b < B; b += 64) {
+        if (D_::ld(a + b) > 0.f) s += D_::ld(d + b);
+        else d[b] = (T)0;
+    }
+    s = wave_sum(s);
+    if (lane == 0) D_::st(reinterpret_cast<T*>(e_b) + j, s);
+}
+
+// dst[idx[j]][:] = round(dst[idx[j]][:] + src[j][:]) for j < n: what `grad[dead] += rows` does on a dense gradient
+// (unique indices: no atomics).  A = 1 handles the bias vector.
+template <int DT>
+__global__ __launch_bounds__(256) void rows_scatter_add_kernel(int n, int A, const int32_t* __restrict__ idx, const void* __restrict__ src_,
+                                                               long long ld_src, void* __restrict__ dst_, long long ld_dst,
+                                                               const int32_t* __restrict__ n_dev, int dst_rows) {
+    typedef DType<DT> D_;
+    typedef typename D_::T T;
+    const int j = blockIdx.x;
+    if (j >= n || (n_dev && j >= *n_dev)) return;
+    if (idx[j] < 0 || idx[j] >= dst_rows) return;          // never dereference an index outside the destination
+    const T* src = reinterpret_cast<const T*>(src_) + (size_t)j * ld_src;
+    T* dst = reinterpret_cast<T*>(dst_) + (size_t)idx[j] * ld_dst;
+    for (int c = threadIdx.x; c < A; c += 256) D_::st(dst + c, D_::ld(dst + c) + D_::ld(src + c));
+}
+
 }  // namespace mtc
 
 using namespace mtc;
 
+extern "C" int mtc_transpose_rows(int32_t dtype, int32_t R, int32_t C, int32_t R_pad, const void* src, int64_t ld_src,
+                                  const int32_t* src_rows, void* dst, int64_t ld_dst, void* stream) {
+    MTC_REQUIRE(dtype == MTC_F32 || dtype == MTC_BF16, "mtc_transpose_rows: bad dtype %d", dtype);
+    MTC_REQUIRE(R >= 0 && C >= 0 && R_pad >= R && ld_src >= C && ld_dst >= R_pad, "mtc_transpose_rows: bad sizes");
+    if (C == 0 || R_pad == 0) return 0;
+    MTC_REQUIRE(src && dst, "mtc_transpose_rows: null pointer");
+    const dim3 grid((R_pad + 63) / 64, (C + 63) / 64), block(256);
+    if (dtype == MTC_BF16)
+        hipLaunchKernelGGL(transpose_rows_kernel<u16>, grid, block, 0, as_stream(stream), R, C, R_pad, (const u16*)src,
+                           (long long)ld_src, src_rows, (u16*)dst, (long long)ld_dst);
+    else
+        hipLaunchKernelGGL(transpose_rows_kernel<float>, grid, block, 0, as_stream(stream), R, C, R_pad, (const float*)src,
+                           (long long)ld_src, src_rows, (float*)dst, (long long)ld_dst);
+    return check_launch("mtc_transpose_rows");
+}
+
+extern "C" int mtc_aux_mask_rowsum(int32_t dtype, int32_t n, int32_t B, const void* acts_auxT, int64_t ld_a, void* d_actsT,
+                                   int64_t ld_d, void* e_b, void* stream) {
+    MTC_REQUIRE(dtype == MTC_F32 || dtype == MTC_BF16, "mtc_aux_mask_rowsum: bad dtype %d", dtype);
+    if (n <= 0) return 0;
+    MTC_REQUIRE(acts_auxT && d_actsT && e_b && B > 0 && ld_a >= B && ld_d >= B, "mtc_aux_mask_rowsum: bad arguments");
+    const dim3 grid((n + 3) / 4), block(256);
+    if (dtype == MTC_BF16)
+        hipLaunchKernelGGL(aux_mask_rowsum_kernel<MTC_BF16>, grid, block, 0, as_stream(stream), n, B, acts_auxT, (long long)ld_a,
+                           d_actsT, (long long)ld_d, e_b);
+    else
+        hipLaunchKernelGGL(aux_mask_rowsum_kernel<MTC_F32>, grid, block, 0, as_stream(stream), n, B, acts_auxT, (long long)ld_a,
+                           d_actsT, (long long)ld_d, e_b);
+    return check_launch("mtc_aux_mask_rowsum");
+}
+
+extern "C" int mtc_rows_scatter_add(int32_t dtype, int32_t n, int32_t A, const int32_t* idx, const void* src, int64_t ld_src,
+                                    void* dst, int64_t ld_dst, int32_t dst_rows, const int32_t* n_dev, void* stream) {
+    MTC_REQUIRE(dtype == MTC_F32 || dtype == MTC_BF16, "mtc_rows_scatter_add: bad dtype %d", dtype);
+    if (n <= 0 || A <= 0) return 0;
+    MTC_REQUIRE(idx && src && dst && ld_src >= A && ld_dst >= A && dst_rows > 0, "mtc_rows_scatter_add: bad arguments");
+    if (dtype == MTC_BF16)
+        hipLaunchKernelGGL(rows_scatter_add_kernel<MTC_BF16>, dim3(n), dim3(256), 0, as_stream(stream), n, A, idx, src,
+                           (long long)ld_src, dst, (long long)ld_dst, n_dev, dst_rows);
+    else
+        hipLaunchKernelGGL(rows_scatter_add_kernel<MTC_F32>, dim3(n), dim3(256), 0, as_stream(stream), n, A, idx, src,
+                           (long long)ld_src, dst, (long long)ld_dst, n_dev, dst_rows);
+    return check_launch("mtc_rows_scatter_add");
+}
+
 extern "C" int mtc_aux_dead_list(const mtc_desc* d, const float* cnt, float n_batches_to_dead, int32_t* dead_idx,
-                                 int32_t* n_dead_dev, void* stream) {
+                                 int32_t* n_dead_dev, int32_t* row_map, int32_t* next_bound_dev, void* stream) {
     if (check_desc(d, "mtc_aux_dead_list")) return -1;
     MTC_REQUIRE(cnt && dead_idx && n_dead_dev, "mtc_aux_dead_list: null pointer");
-    hipLaunchKernelGGL(dead_list_kernel, dim3(1), dim3(1024), 0, as_stream(stream), d->D, cnt, n_batches_to_dead, dead_idx,
-                       n_dead_dev);
+    const size_t lds = (size_t)((d->D + 1023) / 1024) * 16 * sizeof(uint32_t);
+    MTC_REQUIRE(lds <= 48 * 1024, "mtc_aux_dead_list: D = %d is beyond the 786432 features one launch lists", d->D);
+    hipLaunchKernelGGL(dead_list_kernel, dim3(1), dim3(1024), lds, as_stream(stream), d->D, cnt, n_batches_to_dead, dead_idx,
+                       n_dead_dev, row_map, next_bound_dev);
     return check_launch("mtc_aux_dead_list");
 }
 
@@ -374,7 +534,7 @@ extern "C" int mtc_aux_fwd(const mtc_desc* d, const int32_t* row_ptr, const int3
     const float coef_aux = (float)(2.0 * (double)aux_penalty / ((double)d->B * (double)d->A_t));
     DISPATCH_NC(d->dtype, nc_for(d->A_t), aux_fwd_kernel, dim3((d->B + 3) / 4), dim3(256), as_stream(stream), d->B, d->A_t,
                 d->unit_norm, coef_aux, row_ptr, col_idx, vals, W_dec, x_target, x_hat, std, g, g_aux, aux_rows, d_aux_vals,
-                (const void*)nullptr);
+                (const void*)nullptr, (const int32_t*)nullptr);
     return check_launch("mtc_aux_fwd");
 }
 
@@ -425,14 +585,15 @@ extern "C" int mtc_aux_count_at(const mtc_desc* d, const void* acts, const int32
 }
 
 extern "C" int mtc_aux_residual(const mtc_desc* d, const void* x_hat_aux, const void* x_target, const void* x_hat,
-                                const void* std, float aux_penalty, void* g, void* g_aux, float* aux_rows, void* stream) {
+                                const void* std, float aux_penalty, void* g, void* g_aux, float* aux_rows,
+                                const int32_t* active_dev, void* stream) {
     if (check_desc(d, "mtc_aux_residual")) return -1;
     MTC_REQUIRE(x_hat_aux && x_target && x_hat && aux_rows, "mtc_aux_residual: null pointer");
     MTC_REQUIRE(!d->unit_norm || std, "mtc_aux_residual: unit_norm needs std");
     const float coef_aux = (float)(2.0 * (double)aux_penalty / ((double)d->B * (double)d->A_t));
     DISPATCH_NC(d->dtype, nc_for(d->A_t), aux_fwd_kernel, dim3((d->B + 3) / 4), dim3(256), as_stream(stream), d->B, d->A_t,
                 d->unit_norm, coef_aux, (const int32_t*)nullptr, (const int32_t*)nullptr, (const void*)nullptr,
-                (const void*)nullptr, x_target, x_hat, std, g, g_aux, aux_rows, (float*)nullptr, x_hat_aux);
+                (const void*)nullptr, x_target, x_hat, std, g, g_aux, aux_rows, (float*)nullptr, x_hat_aux, active_dev);
     return check_launch("mtc_aux_residual");
 }
 

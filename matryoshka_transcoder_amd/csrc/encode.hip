@@ -119,9 +119,16 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
+// EPI 0: the encoder (round, + bias, round, ReLU / threshold; lda = ldb = K, ldc = N).  EPI 1 / 2: plain C = A . Bt^T
+// (mtc_gemm_nt: the auxiliary branch's products) rounded once to bf16 / kept in fp32, with row strides lda / ldb / ldc
+// and an optional row gather on A (a_rows: A's row m is A[a_rows[m]]).
+template <int EPI>
 __global__ __launch_bounds__(256, 2) void encode_bf16_mfma_kernel(const u16* __restrict__ X, const u16* __restrict__ Wt,
-                                                                  const u16* __restrict__ bias, u16* __restrict__ acts,
-                                                                  int M, int N, int K, int mt, int nt, const void* __restrict__ thr) {
+                                                                  const u16* __restrict__ bias, void* __restrict__ acts_,
+                                                                  int M, int N, int K, int mt, int nt, const void* __restrict__ thr,
+                                                                  long long lda, long long ldb, long long ldc,
+                                                                  const int32_t* __restrict__ a_rows) {
+    u16* acts = reinterpret_cast<u16*>(acts_);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // layout: [stage][operand(0 = X, 1 = W)][128 rows][128 B]
     int tm, tn;
@@ -139,9 +146,11 @@ __global__ __launch_bounds__(256, 2) void encode_bf16_mfma_kernel(const u16* __r
     for (int p = 0; p < 4; ++p) {
         const int r = (wid * 4 + p) * 8 + srow;      // row inside the tile
         const int chunk = (lane & 7) ^ ((r >> 1) & 7);
-        const int xr = min(row0 + r, M - 1), wr = min(col0 + r, N - 1);   // clamp: tails read valid rows
-        xsrc[p] = X + (size_t)xr * K + chunk * 8;
-        wsrc[p] = Wt + (size_t)wr * K + chunk * 8;
+        int xr = min(row0 + r, M - 1);                                    // clamp: tails read valid rows
+        const int wr = min(col0 + r, N - 1);
+        if (EPI != 0 && a_rows) xr = a_rows[xr];
+        xsrc[p] = X + (size_t)xr * (EPI == 0 ? (long long)K : lda) + chunk * 8;
+        wsrc[p] = Wt + (size_t)wr * (EPI == 0 ? (long long)K : ldb) + chunk * 8;
     }
     auto stage = [&](int buf, int kt) {
         char* base = smem + buf * 2 * TILE_BYTES;
@@ -197,6 +206,27 @@ __global__ __launch_bounds__(256, 2) void encode_bf16_mfma_kernel(const u16* __r
     // ---- epilogue: lane holds features f = fbase + i*16 + fq*4 + r (r = 0..3) of batch row b = bbase + j*16 + fr
     const int fbase = col0 + wf * 64 + fq * 4;
     const int bbase = row0 + wb * 64 + fr;
+    if (EPI != 0) {                               // plain product (N % 4 == 0, ldc % 4 == 0: checked on the host)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = fbase + i * 16;
+            if (f >= N) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int b = bbase + j * 16;
+                if (b >= M) continue;
+                const f32x4 v = acc[i][j];
+                if (EPI == 2) {
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(acts_) + (size_t)b * ldc + f) = v;
+                } else {
+                    uint2 o;
+                    o.x = pack2_bf16(v[0], v[1]); o.y = pack2_bf16(v[2], v[3]);
+                    *reinterpret_cast<uint2*>(acts + (size_t)b * ldc + f) = o;
+                }
+            }
+        }
+        return;
+    }
     const float fl = epilogue_floor<MTC_BF16>(thr);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -224,9 +254,12 @@ __global__ __launch_bounds__(256, 2) void encode_bf16_mfma_kernel(const u16* __r
 // group consumes component c, so the four lane groups (lane >> 4) feed k = 16 g + 4 q + c -- a
 // permutation of k that is the same for both operands, which is all a dot product needs.
 constexpr int BK32 = 32;
+template <int EPI>
 __global__ __launch_bounds__(256, 2) void encode_f32_mfma_kernel(const float* __restrict__ X, const float* __restrict__ Wt,
                                                                  const float* __restrict__ bias, float* __restrict__ acts,
-                                                                 int M, int N, int K, int mt, int nt, const void* __restrict__ thr) {
+                                                                 int M, int N, int K, int mt, int nt, const void* __restrict__ thr,
+                                                                 long long lda, long long ldb, long long ldc,
+                                                                 const int32_t* __restrict__ a_rows) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int tm, tn;
     xcd_tile_coords(blockIdx.x, mt * nt, mt, nt, tm, tn);
@@ -241,9 +274,11 @@ __global__ __launch_bounds__(256, 2) void encode_f32_mfma_kernel(const float* __
     for (int p = 0; p < 4; ++p) {
         const int r = (wid * 4 + p) * 8 + srow;
         const int chunk = (lane & 7) ^ ((r >> 1) & 7);
-        const int xr = min(row0 + r, M - 1), wr = min(col0 + r, N - 1);
-        xsrc[p] = X + (size_t)xr * K + chunk * 4;
-        wsrc[p] = Wt + (size_t)wr * K + chunk * 4;
+        int xr = min(row0 + r, M - 1);
+        const int wr = min(col0 + r, N - 1);
+        if (EPI != 0 && a_rows) xr = a_rows[xr];
+        xsrc[p] = X + (size_t)xr * (EPI == 0 ? (long long)K : lda) + chunk * 4;
+        wsrc[p] = Wt + (size_t)wr * (EPI == 0 ? (long long)K : ldb) + chunk * 4;
     }
     auto stage = [&](int buf, int kt) {
         char* base = smem + buf * 2 * TILE_BYTES;
@@ -298,20 +333,25 @@ __global__ __launch_bounds__(256, 2) void encode_f32_mfma_kernel(const float* __
     // ---- epilogue: lane holds features f = fbase + i*16 + r (r = 0..3) of batch row b = bbase + j*16
     const int fbase = col0 + wf * 64 + fq * 4;
     const int bbase = row0 + wb * 64 + fr;
-    const float fl = epilogue_floor<MTC_F32>(thr);
+    const float fl = EPI == 0 ? epilogue_floor<MTC_F32>(thr) : 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int f = fbase + i * 16;
         if (f >= N) continue;
-        const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + f);
+        f32x4 bb = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (EPI == 0) bb = *reinterpret_cast<const f32x4*>(bias + f);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int b = bbase + j * 16;
             if (b >= M) continue;
             f32x4 v = acc[i][j];
+            if (EPI == 0) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { const float pre = v[r] + bb[r]; v[r] = pre > fl ? pre : 0.f; }
-            *reinterpret_cast<f32x4*>(acts + (size_t)b * N + f) = v;
+                for (int r = 0; r < 4; ++r) { const float pre = v[r] + bb[r]; v[r] = pre > fl ? pre : 0.f; }
+                *reinterpret_cast<f32x4*>(acts + (size_t)b * N + f) = v;
+            } else {
+                *reinterpret_cast<f32x4*>(acts + (size_t)b * ldc + f) = v;
+            }
         }
     }
 }
@@ -780,10 +820,12 @@ __global__ __launch_bounds__(512, 1) void encode_bf16_mfma256p_kernel(const u16*
 // ------------------------------------------------------------------------------------------- K1 generic
 // Any shape / dtype (fp32 model dtype, and bf16 shapes whose K is not a multiple of 64).
 // 64x64 tile, 16-deep k slices, 4x4 outputs per thread, fp32 FMA.
-template <int DT>
+template <int DT, int EPI>
 __global__ __launch_bounds__(256) void encode_generic_kernel(const void* __restrict__ X, const void* __restrict__ Wt,
                                                              const void* __restrict__ bias, void* __restrict__ acts,
-                                                             int M, int N, int K, const void* __restrict__ thr) {
+                                                             int M, int N, int K, const void* __restrict__ thr,
+                                                             long long lda, long long ldb, long long ldc,
+                                                             const int32_t* __restrict__ a_rows) {
     typedef DType<DT> D_;
     typedef typename D_::T T;
     __shared__ float xs[16][64 + 4];
@@ -798,8 +840,15 @@ __global__ __launch_bounds__(256) void encode_generic_kernel(const void* __restr
         for (int i = tid; i < 64 * 16; i += 256) {
             const int r = i >> 4, k = i & 15;
             const bool kin = (k0 + k) < K;
-            xs[k][r] = (kin && row0 + r < M) ? D_::ld(Xp + (size_t)(row0 + r) * K + k0 + k) : 0.f;
-            ws[k][r] = (kin && col0 + r < N) ? D_::ld(Wp + (size_t)(col0 + r) * K + k0 + k) : 0.f;
+            if (EPI == 0) {
+                xs[k][r] = (kin && row0 + r < M) ? D_::ld(Xp + (size_t)(row0 + r) * K + k0 + k) : 0.f;
+                ws[k][r] = (kin && col0 + r < N) ? D_::ld(Wp + (size_t)(col0 + r) * K + k0 + k) : 0.f;
+            } else {
+                const bool xin = kin && row0 + r < M;
+                const long long xr = xin ? (a_rows ? (long long)a_rows[row0 + r] : (long long)(row0 + r)) : 0;
+                xs[k][r] = xin ? D_::ld(Xp + (size_t)xr * lda + k0 + k) : 0.f;
+                ws[k][r] = (kin && col0 + r < N) ? D_::ld(Wp + (size_t)(col0 + r) * ldb + k0 + k) : 0.f;
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -816,7 +865,7 @@ __global__ __launch_bounds__(256) void encode_generic_kernel(const void* __restr
     }
     T* out = reinterpret_cast<T*>(acts);
     const T* bp = reinterpret_cast<const T*>(bias);
-    const float fl = epilogue_floor<DT>(thr);
+    const float fl = EPI == 0 ? epilogue_floor<DT>(thr) : 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = row0 + ty * 4 + i;
@@ -825,8 +874,14 @@ __global__ __launch_bounds__(256) void encode_generic_kernel(const void* __restr
         for (int j = 0; j < 4; ++j) {
             const int c = col0 + tx * 4 + j;
             if (c >= N) continue;
-            const float pre = D_::rnd(D_::rnd(acc[i][j]) + D_::ld(bp + c));
-            D_::st(out + (size_t)r * N + c, pre > fl ? pre : 0.f);
+            if (EPI == 0) {
+                const float pre = D_::rnd(D_::rnd(acc[i][j]) + D_::ld(bp + c));
+                D_::st(out + (size_t)r * N + c, pre > fl ? pre : 0.f);
+            } else if (EPI == 2) {
+                reinterpret_cast<float*>(acts)[(size_t)r * ldc + c] = acc[i][j];
+            } else {
+                D_::st(out + (size_t)r * ldc + c, acc[i][j]);
+            }
         }
     }
 }
@@ -861,7 +916,7 @@ static void encode_options_once() {
     if (g_f32_generic < 0) g_f32_generic = getenv("MTC_ENCODE_F32_GENERIC") ? 1 : 0;
 }
 constexpr int MAX_DEV = 64;
-static bool g_attr_done[5][MAX_DEV];
+static bool g_attr_done[9][MAX_DEV];
 static int g_cus[MAX_DEV];
 static void lds_opt_in(int which, const void* fn, int lds) {
     int dev = 0;
@@ -901,11 +956,12 @@ static int encode_impl(const mtc_desc* d, const void* x, const void* W_encT, con
     encode_options_once();
     if (d->dtype == MTC_F32 && (K % BK32) == 0 && !g_f32_generic) {
         const int lds = 2 * 2 * TILE_BYTES;
-        lds_opt_in(0, reinterpret_cast<const void*>(encode_f32_mfma_kernel), lds);
+        lds_opt_in(0, reinterpret_cast<const void*>(encode_f32_mfma_kernel<0>), lds);
         const int mt = (M + BM - 1) / BM, nt = (N + BN - 1) / BN;
-        hipLaunchKernelGGL(encode_f32_mfma_kernel, dim3(mt * nt), dim3(256), lds, as_stream(stream),
+        hipLaunchKernelGGL(encode_f32_mfma_kernel<0>, dim3(mt * nt), dim3(256), lds, as_stream(stream),
                            reinterpret_cast<const float*>(x), reinterpret_cast<const float*>(W_encT),
-                           reinterpret_cast<const float*>(b_enc), reinterpret_cast<float*>(acts), M, N, K, mt, nt, thr);
+                           reinterpret_cast<const float*>(b_enc), reinterpret_cast<float*>(acts), M, N, K, mt, nt, thr,
+                           0ll, 0ll, 0ll, (const int32_t*)nullptr);
         return check_launch("mtc_encode_fwd");
     }
     const int big_tiles = ((M + B2M - 1) / B2M) * ((N + B2N - 1) / B2N);
@@ -930,16 +986,19 @@ static int encode_impl(const mtc_desc* d, const void* x, const void* W_encT, con
         }
     } else if (d->dtype == MTC_BF16 && (K % BK) == 0) {
         const int lds = 2 * 2 * TILE_BYTES;
-        lds_opt_in(2, reinterpret_cast<const void*>(encode_bf16_mfma_kernel), lds);
+        lds_opt_in(2, reinterpret_cast<const void*>(encode_bf16_mfma_kernel<0>), lds);
         const int mt = (M + BM - 1) / BM, nt = (N + BN - 1) / BN;
-        hipLaunchKernelGGL(encode_bf16_mfma_kernel, dim3(mt * nt), dim3(256), lds, as_stream(stream),
-                           (const u16*)x, (const u16*)W_encT, (const u16*)b_enc, (u16*)acts, M, N, K, mt, nt, thr);
+        hipLaunchKernelGGL(encode_bf16_mfma_kernel<0>, dim3(mt * nt), dim3(256), lds, as_stream(stream),
+                           (const u16*)x, (const u16*)W_encT, (const u16*)b_enc, acts, M, N, K, mt, nt, thr,
+                           0ll, 0ll, 0ll, (const int32_t*)nullptr);
     } else {
         const dim3 grid((N + 63) / 64, (M + 63) / 64), block(256);
         if (d->dtype == MTC_BF16)
-            hipLaunchKernelGGL(encode_generic_kernel<MTC_BF16>, grid, block, 0, as_stream(stream), x, W_encT, b_enc, acts, M, N, K, thr);
+            hipLaunchKernelGGL((encode_generic_kernel<MTC_BF16, 0>), grid, block, 0, as_stream(stream), x, W_encT, b_enc, acts, M, N, K, thr,
+                               0ll, 0ll, 0ll, (const int32_t*)nullptr);
         else
-            hipLaunchKernelGGL(encode_generic_kernel<MTC_F32>, grid, block, 0, as_stream(stream), x, W_encT, b_enc, acts, M, N, K, thr);
+            hipLaunchKernelGGL((encode_generic_kernel<MTC_F32, 0>), grid, block, 0, as_stream(stream), x, W_encT, b_enc, acts, M, N, K, thr,
+                               0ll, 0ll, 0ll, (const int32_t*)nullptr);
     }
     return check_launch("mtc_encode_fwd");
 }
@@ -956,4 +1015,53 @@ extern "C" int mtc_encode_threshold_infer(const mtc_desc* d, const void* x, cons
     if (check_desc(d, "mtc_encode_threshold_infer")) return -1;
     MTC_REQUIRE(x && W_encT && b_enc && threshold && feats, "mtc_encode_threshold_infer: null pointer");
     return encode_impl(d, x, W_encT, b_enc, threshold, feats, stream);
+}
+
+// C[m][n] = sum_k A[row(m)][k] * Bt[n][k]: the products of the auxiliary branch (sae.py:336-341 and their autograd) on
+// the encoder's own tiles.  fp32 accumulation, ONE rounding to the model dtype (what a matmul of model-dtype tensors
+// gives), or fp32 output (partial sums that are all-reduced over dictionary shards).
+extern "C" int mtc_gemm_nt(int32_t dtype, int32_t M, int32_t N, int32_t K, const void* A, int64_t lda, const int32_t* a_rows,
+                           const void* Bt, int64_t ldb, void* C, int64_t ldc, int32_t out_f32, void* stream) {
+    MTC_REQUIRE(dtype == MTC_F32 || dtype == MTC_BF16, "mtc_gemm_nt: bad dtype %d", dtype);
+    MTC_REQUIRE(M >= 0 && N >= 0 && K > 0, "mtc_gemm_nt: bad sizes M %d N %d K %d", M, N, K);
+    if (M == 0 || N == 0) return 0;
+    MTC_REQUIRE(A && Bt && C, "mtc_gemm_nt: null pointer");
+    MTC_REQUIRE(lda >= K && ldb >= K && ldc >= N, "mtc_gemm_nt: row strides shorter than the rows");
+    encode_options_once();
+    hipStream_t s = as_stream(stream);
+    const int es = dtype == MTC_BF16 ? 2 : 4;
+    const bool aligned = (lda * es) % 16 == 0 && (ldb * es) % 16 == 0 && (N % 4) == 0 && (ldc % 4) == 0 &&
+                         ((uintptr_t)A % 16) == 0 && ((uintptr_t)Bt % 16) == 0 && ((uintptr_t)C % 16) == 0;
+    const int mt = (M + BM - 1) / BM, nt = (N + BN - 1) / BN;
+    const int lds = 2 * 2 * TILE_BYTES;
+    if (dtype == MTC_BF16 && aligned && (K % BK) == 0) {
+        if (out_f32) {
+            lds_opt_in(5, reinterpret_cast<const void*>(encode_bf16_mfma_kernel<2>), lds);
+            hipLaunchKernelGGL(encode_bf16_mfma_kernel<2>, dim3(mt * nt), dim3(256), lds, s, (const u16*)A, (const u16*)Bt,
+                               (const u16*)nullptr, C, M, N, K, mt, nt, (const void*)nullptr, (long long)lda, (long long)ldb,
+                               (long long)ldc, a_rows);
+        } else {
+            lds_opt_in(6, reinterpret_cast<const void*>(encode_bf16_mfma_kernel<1>), lds);
+            hipLaunchKernelGGL(encode_bf16_mfma_kernel<1>, dim3(mt * nt), dim3(256), lds, s, (const u16*)A, (const u16*)Bt,
+                               (const u16*)nullptr, C, M, N, K, mt, nt, (const void*)nullptr, (long long)lda, (long long)ldb,
+                               (long long)ldc, a_rows);
+        }
+    } else if (dtype == MTC_F32 && aligned && (K % BK32) == 0) {
+        lds_opt_in(7, reinterpret_cast<const void*>(encode_f32_mfma_kernel<1>), lds);
+        hipLaunchKernelGGL(encode_f32_mfma_kernel<1>, dim3(mt * nt), dim3(256), lds, s, (const float*)A, (const float*)Bt,
+                           (const float*)nullptr, (float*)C, M, N, K, mt, nt, (const void*)nullptr, (long long)lda, (long long)ldb,
+                           (long long)ldc, a_rows);
+    } else {
+        const dim3 grid((N + 63) / 64, (M + 63) / 64), block(256);
+        if (dtype == MTC_BF16 && out_f32)
+            hipLaunchKernelGGL((encode_generic_kernel<MTC_BF16, 2>), grid, block, 0, s, A, Bt, (const void*)nullptr, C, M, N, K,
+                               (const void*)nullptr, (long long)lda, (long long)ldb, (long long)ldc, a_rows);
+        else if (dtype == MTC_BF16)
+            hipLaunchKernelGGL((encode_generic_kernel<MTC_BF16, 1>), grid, block, 0, s, A, Bt, (const void*)nullptr, C, M, N, K,
+                               (const void*)nullptr, (long long)lda, (long long)ldb, (long long)ldc, a_rows);
+        else
+            hipLaunchKernelGGL((encode_generic_kernel<MTC_F32, 1>), grid, block, 0, s, A, Bt, (const void*)nullptr, C, M, N, K,
+                               (const void*)nullptr, (long long)lda, (long long)ldb, (long long)ldc, a_rows);
+    }
+    return check_launch("mtc_gemm_nt");
 }

@@ -82,6 +82,24 @@ class ForwardResult:
     extra: dict = field(default_factory=dict)
 
 
+class DeadList:
+    """The dead-feature list of one forward (a9).  `counts` = device {n_dead, upper bound of the next forward's n_dead};
+    `host` receives them through an asynchronous copy, `n()` / `next_bound()` wait for that copy only (not for the
+    stream); `cap` = the host-side upper bound of n_dead the launches of this forward are sized with."""
+    __slots__ = ("dead_idx", "counts", "row_map", "host", "event", "cap")
+
+    def __init__(self):
+        self.cap = None
+
+    def n(self) -> int:
+        self.event.synchronize()
+        return int(self.host[0])
+
+    def next_bound(self) -> int:
+        self.event.synchronize()
+        return int(self.host[1])
+
+
 class HotPath:
     """One instance per transcoder; stateless apart from the static problem description."""
 
@@ -93,6 +111,7 @@ class HotPath:
         self.code = dtype_code(dtype)
         self.unit_norm = bool(unit_norm)
         self._carry = {}                 # device -> 8 x uint32 carried lower bound of the TopK threshold
+        self._pinned = {}                # device -> ring of pinned int32[2] (dead-list counts on their way to the host)
 
     def desc(self, B: int):
         return _lib.make_desc(B, self.A_s, self.A_t, self.D, self.prefix, self.code, self.unit_norm)
@@ -261,7 +280,7 @@ class HotPath:
         B = d.B
         dead_idx = torch.empty(self.D, dtype=torch.int32, device=dev)
         n_dead = torch.empty(1, dtype=torch.int32, device=dev)
-        check(lib.mtc_aux_dead_list(C.byref(d), _p(dead_cnt), float(n_batches_to_dead), _p(dead_idx), _p(n_dead), s),
+        check(lib.mtc_aux_dead_list(C.byref(d), _p(dead_cnt), float(n_batches_to_dead), _p(dead_idx), _p(n_dead), None, None, s),
               "mtc_aux_dead_list")
         row_cnt = torch.empty(B, dtype=torch.int32, device=dev)
         row_tau = torch.empty(B, dtype=torch.int32, device=dev)
@@ -288,76 +307,130 @@ class HotPath:
                               float(aux_penalty), _p(g), _p(g_aux), _p(aux_rows), _p(d_aux), s), "mtc_aux_fwd")
         return sel, g_aux, aux_rows, d_aux
 
-    def aux_dead_list(self, d, dead_cnt, n_batches_to_dead: float):
-        """(dead_idx int32[D], n_dead device int32[1], n_dead as a Python int).  Reads the count back: the dense aux
-        form sizes its GEMM operands with it (the reference synchronises at the same place, sae.py:331).  Callers
-        issue this right after the counters are updated and BEFORE the decode launch, so the launches that
-        follow the read-back queue up behind a long kernel instead of leaving the GPU idle."""
+    def aux_dead_list(self, d, dead_cnt, n_batches_to_dead: float) -> "DeadList":
+        """Dead list of this forward (ascending features with cnt >= n_batches_to_dead; the tail of `dead_idx` is
+        gatherable), the feature -> slot map, and -- copied to pinned host memory behind the kernel -- its length and the
+        upper bound of the NEXT forward's length.  Nothing is read back here: `DeadList.n()` waits for that copy only.
+        Callers issue this right after the counters are updated and BEFORE the decode launch."""
         dev = dead_cnt.device
-        dead_idx = torch.empty(self.D, dtype=torch.int32, device=dev)
-        n_dead = torch.empty(1, dtype=torch.int32, device=dev)
-        check(self.lib.mtc_aux_dead_list(C.byref(d), _p(dead_cnt), float(n_batches_to_dead), _p(dead_idx), _p(n_dead),
-                                         _stream()), "mtc_aux_dead_list")
-        return dead_idx, n_dead, int(n_dead.item())
+        dl = DeadList()
+        dl.dead_idx = torch.empty(self.D, dtype=torch.int32, device=dev)
+        dl.counts = torch.empty(2, dtype=torch.int32, device=dev)          # {n_dead, bound of the next forward's n_dead}
+        dl.row_map = torch.empty(self.D, dtype=torch.int32, device=dev)
+        check(self.lib.mtc_aux_dead_list(C.byref(d), _p(dead_cnt), float(n_batches_to_dead), _p(dl.dead_idx), _p(dl.counts),
+                                         _p(dl.row_map), C.c_void_p(dl.counts.data_ptr() + 4), _stream()), "mtc_aux_dead_list")
+        ring = self._pinned.setdefault(str(dev), [[torch.empty(2, dtype=torch.int32).pin_memory() for _ in range(4)], 0])
+        dl.host = ring[0][ring[1] % 4]
+        ring[1] += 1
+        dl.host.copy_(dl.counts, non_blocking=True)
+        dl.event = torch.cuda.Event()
+        dl.event.record(torch.cuda.current_stream())
+        return dl
+
+    @staticmethod
+    def _aux_bucket(n: int, D: int) -> int:
+        """GEMM operand widths come in buckets (n_dead changes almost every step; every new size costs allocator growth);
+        the padding columns are zeros."""
+        step = 128 if n <= 2048 else 512 if n <= 8192 else 2048
+        return max(min((max(n, 1) + step - 1) // step * step, D), 1)
+
+    def gemm_nt(self, M, N, K, A, lda, Bt, ldb, out, ldc, a_rows=None, out_f32=False):
+        check(self.lib.mtc_gemm_nt(self.code, int(M), int(N), int(K), _p(A), int(lda), _p(a_rows), _p(Bt), int(ldb), _p(out),
+                                   int(ldc), int(bool(out_f32)), _stream()), "mtc_gemm_nt")
+        return out
+
+    def transpose_rows(self, src, R, Cc, R_pad=None, src_rows=None):
+        """dst [Cc][R_pad] = src[row(r)][c] transposed (model dtype), zero columns beyond R."""
+        R_pad = R if R_pad is None else R_pad
+        dst = torch.empty(Cc, R_pad, dtype=self.dtype, device=src.device)
+        check(self.lib.mtc_transpose_rows(self.code, int(R), int(Cc), int(R_pad), _p(src), int(src.stride(0)), _p(src_rows),
+                                          _p(dst), int(R_pad), _stream()), "mtc_transpose_rows")
+        return dst
 
     def aux_forward_dense(self, d, acts, dead_cnt, n_batches_to_dead: float, top_k_aux: int, aux_penalty: float, W_dec,
-                          x_target, x_hat, std, g, need_grad: bool, dead=None):
-        """a9 in the reference's own dense form over the compacted dead set (sae.py:332-341), on MFMA: libmtc selects
-        (per-row top-k_aux, ties in dead-list order) and fuses the residual / loss / gradient elementwise part; the
-        [B, n_dead] x [n_dead, A_t] product is a plain library GEMM.  `dead` = the result of aux_dead_list() when the
-        caller already made it.  Returns (ctx dict, aux_rows[B]); g is updated in place."""
+                          x_target, x_hat, std, g, need_grad: bool, dead=None, reduce_partial=None, global_active=None):
+        """a9 in the reference's own dense form over the compacted dead set (sae.py:332-341) on libmtc's MFMA tiles
+        (mtc_gemm_nt; no BLAS library): per-row top-k_aux selection -> acts_aux [B, n_pad] -> x_hat_aux = acts_aux .
+        W_dec[dead] -> residual / loss / g update fused elementwise.  `dead` = aux_dead_list() made by the caller, with
+        `dead.cap` = a host-side upper bound of its length (sizes the launches; the true length stays on the device).
+        `reduce_partial` (sharded dictionary): called on the fp32 partial reconstruction (all-reduce).  Returns
+        (ctx dict, aux_rows[B]); g is updated in place."""
         dev = acts.device
         lib, s = self.lib, _stream()
         B = d.B
-        dead_idx, n_dead, n = dead if dead is not None else self.aux_dead_list(d, dead_cnt, n_batches_to_dead)
-        if n == 0:
+        if dead is None:
+            dead = self.aux_dead_list(d, dead_cnt, n_batches_to_dead)
+        if dead.cap is None:
+            dead.cap = dead.n()
+        if dead.cap == 0 and reduce_partial is None:
             return None, None            # no dead feature after all (sae.py:331: the branch returns a zero)
+        dead_idx, n_dead = dead.dead_idx, dead.counts
         row_cnt = torch.empty(B, dtype=torch.int32, device=dev)
         row_tau = torch.empty(B, dtype=torch.int32, device=dev)
         row_quota = torch.empty(B, dtype=torch.int32, device=dev)
         check(lib.mtc_aux_select(C.byref(d), _p(acts), _p(dead_idx), _p(n_dead), int(top_k_aux), _p(row_cnt), _p(row_tau),
                                  _p(row_quota), s), "mtc_aux_select")
-        # operand sizes come in buckets: n_dead changes almost every step, and every new GEMM shape / allocation size
-        # costs milliseconds once (hipBLASLt solution lookup, allocator growth); the padding columns are zeros
-        step = 128 if n <= 2048 else 512 if n <= 8192 else 2048
-        n_pad = min((n + step - 1) // step * step, self.D)
-        idx = dead_idx[:n].long()
+        n_pad = self._aux_bucket(dead.cap, self.D)
         acts_aux = torch.empty(B, n_pad, dtype=self.dtype, device=dev)
         check(lib.mtc_aux_dense_fill(C.byref(d), _p(acts), _p(dead_idx), _p(n_dead), _p(row_tau), _p(row_quota), n_pad,
                                      _p(acts_aux), s), "mtc_aux_dense_fill")
-        # rows >= n of W_dead only ever meet zero activations / masked gradients: any valid row will do
-        W_dead = W_dec.index_select(0, dead_idx[:n_pad].clamp(0, self.D - 1).long())
-        x_hat_aux = torch.matmul(acts_aux, W_dead)                     # hipBLASLt, fp32 accumulate, one rounding
+        return self._aux_dense_tail(d, dead, acts_aux, n_pad, aux_penalty, W_dec, x_target, x_hat, std, g, need_grad,
+                                    reduce_partial, n_dead if global_active is None else global_active)
+
+    def _aux_dense_tail(self, d, dead, acts_aux, n_pad, aux_penalty, W_dec, x_target, x_hat, std, g, need_grad,
+                        reduce_partial, active):
+        dev, B = acts_aux.device, d.B
+        # W_dec[dead]^T (rows >= n_dead meet zero activations only): gather + transpose in one pass, then the product
+        W_deadT = self.transpose_rows(W_dec, n_pad, self.A_t, src_rows=dead.dead_idx)             # [A_t][n_pad]
+        if reduce_partial is None:
+            x_hat_aux = torch.empty(B, self.A_t, dtype=self.dtype, device=dev)
+            self.gemm_nt(B, self.A_t, n_pad, acts_aux, n_pad, W_deadT, n_pad, x_hat_aux, self.A_t)   # fp32 accumulate, one rounding
+        else:
+            part = torch.empty(B, self.A_t, dtype=torch.float32, device=dev)
+            self.gemm_nt(B, self.A_t, n_pad, acts_aux, n_pad, W_deadT, n_pad, part, self.A_t, out_f32=True)
+            x_hat_aux = reduce_partial(part).to(self.dtype)
         g_aux = torch.empty(B, self.A_t, dtype=self.dtype, device=dev)
         aux_rows = torch.empty(B, dtype=torch.float32, device=dev)
-        check(lib.mtc_aux_residual(C.byref(d), _p(x_hat_aux), _p(x_target), _p(x_hat), _p(std), float(aux_penalty), _p(g),
-                                   _p(g_aux), _p(aux_rows), s), "mtc_aux_residual")
-        ctx = dict(dense=True, n=n)
+        check(self.lib.mtc_aux_residual(C.byref(d), _p(x_hat_aux), _p(x_target), _p(x_hat), _p(std), float(aux_penalty), _p(g),
+                                        _p(g_aux), _p(aux_rows), _p(active), _stream()), "mtc_aux_residual")
+        ctx = dict(dense=True, dead=dead, n_pad=n_pad)
         if need_grad:
-            ctx.update(idx=idx, acts_aux=acts_aux, W_dead=W_dead, g_aux=g_aux)
+            ctx.update(acts_aux=acts_aux, g_aux=g_aux, W_dec=W_dec)
         return ctx, aux_rows
 
     def aux_extra_rows(self, ctx, x_norm, g_loss=None):
-        """Gradient rows of the aux branch over the dead set (model dtype, one rounding per GEMM like the reference's
-        matmul backward): (E_dec [n_pad, A_t], E_enc [n_pad, A_s], e_b [n_pad]); rows >= n are zero."""
-        acts_aux, g_aux = ctx["acts_aux"], ctx["g_aux"]
+        """Gradient rows of the aux branch over the dead set (model dtype, one rounding per product like the reference's
+        matmul backward), every product on mtc_gemm_nt in the feature-major layout the fused gradient kernels read:
+        (E_dec [n_pad, A_t], E_enc [n_pad, A_s], e_b [n_pad]); rows of the padding are never referenced."""
+        acts_aux, g_aux, dead, n_pad, W_dec = ctx["acts_aux"], ctx["g_aux"], ctx["dead"], ctx["n_pad"], ctx["W_dec"]
+        B, dev = acts_aux.shape[0], acts_aux.device
         if g_loss is not None:
             g_aux = (g_aux.float() * g_loss.reshape(()).float()).to(self.dtype)
-        d_acts = torch.matmul(g_aux, ctx["W_dead"].t())                 # [B, n_pad]
-        check(self.lib.mtc_aux_mask(self.code, d_acts.numel(), _p(acts_aux), _p(d_acts), _stream()), "mtc_aux_mask")
-        return torch.matmul(acts_aux.t(), g_aux), torch.matmul(d_acts.t(), x_norm), d_acts.sum(0)
+        # d_acts^T [n_pad][B] = W_dec[dead] . g_aux^T, masked by the selection, and its row sums (b_enc elements)
+        d_actsT = torch.empty(n_pad, B, dtype=self.dtype, device=dev)
+        self.gemm_nt(n_pad, B, self.A_t, W_dec, self.A_t, g_aux, self.A_t, d_actsT, B, a_rows=dead.dead_idx)
+        acts_auxT = self.transpose_rows(acts_aux, B, n_pad)                                        # [n_pad][B]
+        e_b = torch.empty(n_pad, dtype=self.dtype, device=dev)
+        check(self.lib.mtc_aux_mask_rowsum(self.code, n_pad, B, _p(acts_auxT), B, _p(d_actsT), B, _p(e_b), _stream()),
+              "mtc_aux_mask_rowsum")
+        g_auxT = self.transpose_rows(g_aux, B, self.A_t)                                           # [A_t][B]
+        x_normT = self.transpose_rows(x_norm, B, self.A_s)                                         # [A_s][B]
+        E_dec = torch.empty(n_pad, self.A_t, dtype=self.dtype, device=dev)
+        E_enc = torch.empty(n_pad, self.A_s, dtype=self.dtype, device=dev)
+        self.gemm_nt(n_pad, self.A_t, B, acts_auxT, B, g_auxT, B, E_dec, self.A_t)
+        self.gemm_nt(n_pad, self.A_s, B, d_actsT, B, x_normT, B, E_enc, self.A_s)
+        return E_dec, E_enc, e_b
 
     def aux_backward_dense(self, ctx, x_norm, g_loss, grads):
         """Gradients of the aux branch accumulated into materialised dense gradients (the autograd path): rows land at
         the dead features' positions (unique indices: deterministic)."""
         dW_dec, dW_encT, db_enc, db_dec = grads
-        n, idx = ctx["n"], ctx["idx"]
-        if n == 0:
-            return grads
+        dead, n_pad = ctx["dead"], ctx["n_pad"]
         E_dec, E_enc, e_b = self.aux_extra_rows(ctx, x_norm, g_loss)
-        dW_dec.index_add_(0, idx, E_dec[:n])
-        dW_encT.index_add_(0, idx, E_enc[:n])
-        db_enc.index_add_(0, idx, e_b[:n])
+        s = _stream()
+        for dst, src, A in ((dW_dec, E_dec, self.A_t), (dW_encT, E_enc, self.A_s), (db_enc, e_b, 1)):
+            check(self.lib.mtc_rows_scatter_add(self.code, n_pad, A, _p(dead.dead_idx), _p(src), A, _p(dst), A, self.D,
+                                                _p(dead.counts), s), "mtc_rows_scatter_add")
         return grads
 
     # ------------------------------------------------------------------ a12 / a13

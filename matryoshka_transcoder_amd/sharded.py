@@ -80,16 +80,6 @@ def tie_before(all_eq: torch.Tensor, rank: int) -> torch.Tensor:
     return (earlier_rows + earlier_ranks).to(torch.int32)
 
 
-def _mm_f32(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-    """a @ b with an fp32 result (partial sums that are all-reduced must not be rounded to bf16 first)."""
-    if a.dtype == torch.float32:
-        return torch.mm(a, b)
-    try:
-        return torch.mm(a, b, out_dtype=torch.float32)
-    except (TypeError, RuntimeError, NotImplementedError):
-        return torch.mm(a.float(), b.float())
-
-
 class _Comm:
     """torch.distributed on device tensors.  backend "nccl" is RCCL on ROCm; with "gloo" (tests)
     device tensors are staged through the host."""
@@ -263,7 +253,8 @@ class ShardedMatryoshkaTranscoder(MatryoshkaTranscoder):
         B, A_t, Dl, W = d.B, hp.A_t, hp.D, comm.world
         k_aux = int(cfg["top_k_aux"])
         k_pad = (k_aux + 7) // 8 * 8
-        dead_idx, n_dead, n = hp.aux_dead_list(d, self._cnt, float(cfg["n_batches_to_dead"]))
+        dead = hp.aux_dead_list(d, self._cnt, float(cfg["n_batches_to_dead"]))
+        dead_idx, n_dead = dead.dead_idx, dead.counts
         i32 = dict(dtype=torch.int32, device=dev)
         row_cnt, row_tau, row_quota = (torch.empty(B, **i32) for _ in range(3))
         check(lib.mtc_aux_select(C.byref(d), _p(acts), _p(dead_idx), _p(n_dead), k_aux, _p(row_cnt), _p(row_tau), _p(row_quota), s),
@@ -284,25 +275,18 @@ class ShardedMatryoshkaTranscoder(MatryoshkaTranscoder):
         all_eq = comm.all_gather(eq_loc)                                         # [world, B]
         before = all_eq[:comm.rank].sum(0, dtype=torch.int32) if comm.rank > 0 else torch.zeros(B, **i32)
         take = torch.minimum((g_quota - before).clamp_min(0), eq_loc).contiguous()
-        # local part of acts_aux over the local dead set (bucketed width, zero padding), local GEMM, fp32 all-reduce
-        step = 128 if n <= 2048 else 512 if n <= 8192 else 2048
-        n_pad = max(min((n + step - 1) // step * step, Dl), 8)
+        # local part of acts_aux over the local dead set (bucketed width, zero padding), local product on libmtc's own
+        # MFMA tiles with an fp32 result, fp32 all-reduce.  The local count sizes local launches only (the collectives
+        # have fixed shapes), so it is the one read-back of this branch -- by now long on the host (copy issued above)
+        dead.cap = dead.n()
+        n_pad = hp._aux_bucket(dead.cap, Dl)
         acts_aux = torch.empty(B, n_pad, dtype=self.dtype, device=dev)
         check(lib.mtc_aux_dense_fill(C.byref(d), _p(acts), _p(dead_idx), _p(n_dead), _p(g_tau), _p(take), n_pad, _p(acts_aux), s),
               "mtc_aux_dense_fill")
-        W_dead = W_dec.index_select(0, dead_idx[:n_pad].clamp(0, Dl - 1).long())
-        part = _mm_f32(acts_aux, W_dead)
-        comm.all_reduce(part)
-        x_hat_aux = part.to(self.dtype)
-        g_aux = torch.empty(B, A_t, dtype=self.dtype, device=dev)
-        aux_rows = torch.empty(B, dtype=torch.float32, device=dev)
         std = self.x_std.reshape(-1).contiguous() if hp.unit_norm else None
-        dr = _lib.make_desc(B, hp.A_s, hp.A_t, Dl, hp.prefix, hp.code, hp.unit_norm)
-        check(lib.mtc_aux_residual(C.byref(dr), _p(x_hat_aux), _p(x_target), _p(x_hat), _p(std), float(cfg["aux_penalty"]), _p(g),
-                                   _p(g_aux), _p(aux_rows), s), "mtc_aux_residual")
-        ctx = dict(dense=True, n=n)
-        if need_grad:
-            ctx.update(idx=dead_idx[:n].long(), acts_aux=acts_aux, W_dead=W_dead, g_aux=g_aux)
+        ctx, aux_rows = hp._aux_dense_tail(d, dead, acts_aux, n_pad, float(cfg["aux_penalty"]), W_dec, x_target, x_hat, std, g,
+                                           need_grad, comm.all_reduce, None)
+        ctx["local_counts_decide"] = False          # "dead features exist" is global here (_aux_may_be_active), not this shard's count
         return ctx, aux_rows
 
     def _run_aux_sparse(self, hp, d, acts, sel, W_dec, x_target, x_hat, g, need_grad, l1_term):
@@ -341,7 +325,7 @@ class ShardedMatryoshkaTranscoder(MatryoshkaTranscoder):
         # CSR of the local aux entries (ascending local feature inside a row), same kernels as the single-GPU path
         dead_idx = torch.empty(Dl, dtype=torch.int32, device=dev)
         n_dead = torch.empty(1, dtype=torch.int32, device=dev)
-        check(lib.mtc_aux_dead_list(C.byref(d), _p(self._cnt), n_to_dead, _p(dead_idx), _p(n_dead), s), "mtc_aux_dead_list")
+        check(lib.mtc_aux_dead_list(C.byref(d), _p(self._cnt), n_to_dead, _p(dead_idx), _p(n_dead), None, None, s), "mtc_aux_dead_list")
         st = torch.empty(16, dtype=torch.int32, device=dev)
         zeros = torch.zeros(B, dtype=torch.int32, device=dev)
         row_ptr = torch.empty(B + 1, dtype=torch.int32, device=dev)

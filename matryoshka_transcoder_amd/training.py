@@ -96,9 +96,7 @@ class FusedAdam(torch.optim.Optimizer):
         if res.aux is not None and res.aux.get("dense") and res.d_vals is None:
             # dense aux branch: its gradient rows over the dead set (three GEMMs) ride into the fused kernels
             a = res.aux
-            row_map = torch.full((hp.D,), -1, dtype=torch.int32, device=res.g.device)      # hp.D: the local dictionary of a shard
-            row_map[a["idx"]] = torch.arange(a["n"], dtype=torch.int32, device=res.g.device)
-            extra = (row_map,) + tuple(t.contiguous() for t in hp.aux_extra_rows(a, res.x_norm))
+            extra = (a["dead"].row_map,) + tuple(hp.aux_extra_rows(a, res.x_norm))      # feature -> slot map made with the dead list
         elif res.aux is not None:
             tc._join_csc()
             if two_streams:

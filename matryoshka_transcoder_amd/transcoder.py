@@ -43,7 +43,7 @@ class _StepFn(torch.autograd.Function):
         module._last_res = res
         ctx.mark_non_differentiable(res.x_hat, res.scalars)
         loss32 = res.scalars[5]
-        loss = loss32.clone() if res.aux is not None else loss32.to(module.dtype)
+        loss = loss32.clone() if module._aux_is_on(res) else loss32.to(module.dtype)
         return loss, res.x_hat, res.scalars
 
     @staticmethod
@@ -95,6 +95,8 @@ class MatryoshkaTranscoder(nn.Module):
         self._side_inputs = None
         self._deferred = None
         self._dead_check_in = 0          # forwards until a dead feature can exist (host-side bound)
+        self._aux_bound = None           # upper bound of the next forward's dead count (from the last forward's dead list)
+        self._fwd_serial = 0
         self.to(cfg["dtype"]).to(cfg["device"])
 
     # ------------------------------------------------------------------ plumbing
@@ -111,11 +113,13 @@ class MatryoshkaTranscoder(nn.Module):
         """Dead-feature counters (sae.py:134).  Handing the tensor out (or replacing it) voids the
         host-side "no feature can be dead yet" bound, because the caller may edit it in place."""
         self._dead_check_in = 0
+        self._aux_bound = None
         return self._cnt
 
     @num_batches_not_active.setter
     def num_batches_not_active(self, value: torch.Tensor) -> None:
         self._dead_check_in = 0
+        self._aux_bound = None
         self._cnt = value
 
     @property
@@ -223,9 +227,8 @@ class MatryoshkaTranscoder(nn.Module):
         the (synchronising) check repeated.  The reference synchronises on every call (sae.py:331)."""
         if self._dead_check_in > 0:
             return False
-        if getattr(self, "_aux_n_dead", 0) > 0:
-            # dead features existed one forward ago: skip this read-back, the dead list built next (_aux_prepare)
-            # reads its own count back and an empty list switches the branch off again
+        if self._aux_bound is not None and self._aux_bound > 0:
+            # the last forward's dead list says how many features CAN be dead now (its counters >= n - 1): no read-back
             return True
         n_dead_at = float(self.config["n_batches_to_dead"])
         mx = float(self._cnt.max().item())
@@ -247,11 +250,17 @@ class MatryoshkaTranscoder(nn.Module):
         """Dense aux form: build the dead list (and read its length back) now, before the decode launch, so that the
         host has a long kernel to queue the aux launches behind.  An empty list switches the branch off."""
         self._aux_dead = None
+        bound, self._aux_bound = self._aux_bound, None
         if not aux_active or self.config.get("aux_mode", "gemm") != "gemm":
             return aux_active
-        self._aux_dead = hp.aux_dead_list(d, self._cnt, float(self.config["n_batches_to_dead"]))
-        self._aux_n_dead = self._aux_dead[2]
-        return self._aux_n_dead > 0
+        dl = hp.aux_dead_list(d, self._cnt, float(self.config["n_batches_to_dead"]))
+        # launch sizes: the bound the previous forward's list left behind, else (first forward of an active stretch,
+        # counters edited from outside) this list's own length, read back once
+        dl.cap = bound if bound is not None else dl.n()
+        if dl.cap == 0:
+            return False
+        self._aux_dead = dl
+        return True
 
     def _run_forward(self, x_source, x_target, W_enc, b_enc, W_dec, b_dec, need_grad: bool):
         self._check_inputs(x_source, x_target)
@@ -298,6 +307,8 @@ class MatryoshkaTranscoder(nn.Module):
                             g=g if need_grad else None, d_vals=d_vals, row_stats=row_stats, scalars=scalars, aux=aux)
         # main-pool temporaries a side-stream launch reads (the loss reduction): alive until the next step has joined
         # the side stream, so the caching allocator cannot hand their blocks to a later main-stream allocation
+        self._fwd_serial += 1
+        res.extra["serial"] = self._fwd_serial
         res.extra["side_stream_inputs"] = self._side_inputs
         self._side_inputs = None
         return res
@@ -389,17 +400,38 @@ class MatryoshkaTranscoder(nn.Module):
             self._deferred = None
             fn()
 
+    def _aux_is_on(self, res) -> bool:
+        """Did the aux branch of this forward see a dead feature (sae.py:331)?  Decides the dtypes of `loss` / `aux_loss`
+        (sae.py:342-347).  With the dense form the launches were sized from an upper bound, so the answer is the dead
+        list's true length: it reached pinned host memory behind a copy that sits BEFORE the decode launch, so in the
+        fused step this waits for an event long past, never for the stream.  The bound the same copy carries sizes the
+        next forward's aux launches."""
+        if res.aux is None:
+            return False
+        on = res.extra.get("aux_on")
+        if on is None:
+            on = True
+            dead = res.aux.get("dead")
+            if dead is not None and res.aux.get("local_counts_decide", True):
+                on = dead.n() > 0
+                if res.extra.get("serial") == self._fwd_serial:      # still the latest forward: its bound holds for the next
+                    self._aux_bound = dead.next_bound()
+                    self._dead_check_in = 0
+            res.extra["aux_on"] = on
+        return on
+
     def _output_dict(self, res, x_target, loss=None):
         """The reference's 11 keys with its dtypes (sae.py:257-269), from the device-resident scalars."""
         self._flush_deferred()
         s, dt = res.scalars, self.dtype
+        aux_on = self._aux_is_on(res)
         # the kernel already rounded l2 / l1 / l1_norm / loss to the model dtype (mtc_reduce_scalars), so ONE conversion of
         # the 16-float vector yields all of them exactly (a no-op for fp32 models); the entries are views of it
         sd = s.to(dt)
         if loss is None:
-            loss = s[5].clone() if res.aux is not None else sd[5]
+            loss = s[5].clone() if aux_on else sd[5]
         # aux inactive: a 0-dim zero in the target dtype (slot 4 holds 0 then); active: fp32 (sae.py:342-347)
-        if res.aux is not None:
+        if aux_on:
             aux_loss = s[4]
         elif x_target.dtype == dt:
             aux_loss = sd[4]

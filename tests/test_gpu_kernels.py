@@ -261,9 +261,13 @@ def test_aux_path_against_oracle(name, aux_mode, gpu_lib):
     B, D = xs.shape[0], cfg["prefix_sizes"][-1]
     if aux_mode == "gemm":
         a = res.aux
-        assert a["dense"] and a["acts_aux"].shape[1] % 8 == 0 and not bool(a["acts_aux"][:, a["n"]:].any())
-        nzr, nzc = torch.nonzero(a["acts_aux"][:, :a["n"]].cpu(), as_tuple=True)
-        got = set((nzr * D + a["idx"].cpu()[nzc]).tolist())
+        n = a["dead"].n()
+        idx = a["dead"].dead_idx[:n].cpu().long()
+        assert a["dense"] and not bool(a["acts_aux"][:, n:].any())
+        assert torch.equal(a["dead"].row_map.cpu()[idx], torch.arange(n, dtype=torch.int32))       # feature -> slot map
+        assert int((a["dead"].row_map >= 0).sum()) == n and not bool(a["dead"].dead_idx[n:].any())  # gatherable tail
+        nzr, nzc = torch.nonzero(a["acts_aux"][:, :n].cpu(), as_tuple=True)
+        got = set((nzr * D + idx[nzc]).tolist())
         assert len(got) == aux["rows"].numel()
     else:
         asel = res.aux["sel"]
