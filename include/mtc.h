@@ -295,12 +295,21 @@ int mtc_fused_backward_adam_dec_extra(const mtc_desc* d, const int32_t* col_ptr,
                                       const int32_t* csc_pos, const void* vals, const void* g, const float* scale,
                                       void* W_dec, void* exp_avg, void* exp_avg_sq, const mtc_adam_hyper* h,
                                       float* d_vals_out, float l1_term, const int32_t* extra_row, const void* extra_rows,
-                                      void* stream);
+                                      int32_t d_vals_csc_order, void* stream);
 int mtc_fused_backward_adam_enc_extra(const mtc_desc* d, const int32_t* col_ptr, const int32_t* csc_row,
                                       const int32_t* csc_pos, const float* d_vals, const void* x_norm, const float* scale,
                                       void* W_encT, void* exp_avg, void* exp_avg_sq, void* b_enc, void* b_exp_avg,
                                       void* b_exp_avg_sq, const mtc_adam_hyper* h, const int32_t* extra_row,
-                                      const void* extra_rows, const void* extra_bias, void* stream);
+                                      const void* extra_rows, const void* extra_bias, int32_t d_vals_csc_order, void* stream);
+/* d_vals_csc_order != 0 (both launches of one step alike): d a_bj is written / read at the entry's CSC index instead of
+ * its CSR position -- the order both launches walk -- and nothing else may read that buffer as CSR-ordered.  extra_row /
+ * extra_rows may be NULL with it (the plain fused step).  With it, bf16 and A_s a multiple of 64 the encoder launch runs
+ * in its COLUMN-SLICED form when the problem is large enough: the parameter matrix is walked slice by slice (256 / 128 /
+ * 64 columns) in an XCD-contiguous order so that the slice of the gather table x [B][A_s] stays in each XCD's L2 and
+ * the k-fold row gathers stop crossing the fabric; same arithmetic per element.  mtc_fused_set_sliced: 0 = automatic
+ * (default; environment MTC_FUSED_SLICED read once), 1 = never, 2 = whenever the shape allows; returns the previous
+ * setting or -1.  Process-wide tuning / test knob, no counterpart in the reference. */
+int mtc_fused_set_sliced(int mode);
 /* projection only (the reference method called on its own, sae.py:155-163) */
 int mtc_unitnorm_project(const mtc_desc* d, void* W_dec, void* grad, void* stream);
 

@@ -72,8 +72,9 @@ PROTOTYPES = {
     "mtc_adam_flat": (C.c_int, [C.c_int32, C.c_size_t, P, P, P, P, HP, P]),
     "mtc_fused_backward_adam_dec": (C.c_int, [DP, P, P, P, P, P, P, P, P, P, HP, P, C.c_float, P]),
     "mtc_fused_backward_adam_enc": (C.c_int, [DP, P, P, P, P, P, P, P, P, P, P, P, P, HP, P]),
-    "mtc_fused_backward_adam_dec_extra": (C.c_int, [DP, P, P, P, P, P, P, P, P, P, HP, P, C.c_float, P, P, P]),
-    "mtc_fused_backward_adam_enc_extra": (C.c_int, [DP, P, P, P, P, P, P, P, P, P, P, P, P, HP, P, P, P, P]),
+    "mtc_fused_backward_adam_dec_extra": (C.c_int, [DP, P, P, P, P, P, P, P, P, P, HP, P, C.c_float, P, P, C.c_int32, P]),
+    "mtc_fused_backward_adam_enc_extra": (C.c_int, [DP, P, P, P, P, P, P, P, P, P, P, P, P, HP, P, P, P, C.c_int32, P]),
+    "mtc_fused_set_sliced": (C.c_int, [C.c_int]),
     "mtc_unitnorm_project": (C.c_int, [DP, P, P, P]),
     "mtc_aux_dead_list": (C.c_int, [DP, P, C.c_float, P, P, P, P, P]),
     "mtc_gemm_nt": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, P, C.c_int64, P, P, C.c_int64, P, C.c_int64, C.c_int32, P]),

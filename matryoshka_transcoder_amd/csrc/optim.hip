@@ -13,6 +13,7 @@
 #include "common.hpp"
 #include "rowops.hpp"
 #include <math.h>
+#include <stdlib.h>
 
 namespace mtc {
 
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(256, (DT == MTC_BF16 ? (NC <= 5 ? MTC_FUSED_WAVES :
     const float* __restrict__ scale_p, void* __restrict__ W, void* __restrict__ m, void* __restrict__ v,
     void* __restrict__ bias, void* __restrict__ m_b, void* __restrict__ v_b, AdamK k, float* __restrict__ d_vals_out,
     float l1_term, const int32_t* __restrict__ extra_row, const void* __restrict__ extra,
-    const void* __restrict__ extra_bias) {
+    const void* __restrict__ extra_bias, int csc_order /* d a_bj indexed by CSC entry instead of CSR position */) {
     typedef DType<DT> D_;
     typedef typename D_::T T;
     RowCtx<DT, NC> rc;
@@ -164,10 +165,13 @@ __global__ __launch_bounds__(256, (DT == MTC_BF16 ? (NC <= 5 ? MTC_FUSED_WAVES :
         if (lane < nb) {
             my_row = csc_row[e0 + lane];
             my_pos = csc_pos[e0 + lane];
-            my_c = DType<COEF_DT>::ld(reinterpret_cast<const typename DType<COEF_DT>::T*>(coef) + my_pos);
+            // encoder rows: the coefficients d a_bj come in the order the decoder launch wrote them
+            const int at = (!PROJECT && csc_order) ? e0 + lane : my_pos;
+            my_c = DType<COEF_DT>::ld(reinterpret_cast<const typename DType<COEF_DT>::T*>(coef) + at);
         }
         csum += my_c;
-        if constexpr (WITH_DOT != 0) accumulate_dot_run<DT, NC>(rc, src, A, my_row, my_c, my_pos, nb, pw, l1_term, d_vals_out, acc);
+        if constexpr (WITH_DOT != 0)
+            accumulate_dot_run<DT, NC>(rc, src, A, my_row, my_c, csc_order ? e0 + lane : my_pos, nb, pw, l1_term, d_vals_out, acc);
         else accumulate_run<DT, NC>(rc, src, A, my_row, my_c, 0, nb, acc);
     }
     // the .grad a dense backward would hold: rounded to the parameter dtype and kept in storage
@@ -262,6 +266,149 @@ __global__ __launch_bounds__(256, (DT == MTC_BF16 ? (NC <= 5 ? MTC_FUSED_WAVES :
     }
 }
 
+
+// Column-sliced form of the encoder-row kernel (fused_grad_adam_kernel<PROJECT = 0>): the same per-feature gradient +
+// Adam, but one launch walks the parameter matrix slice by slice -- LPF lanes (LPF * 8 columns) per feature, 64 / LPF
+// features per wave -- in an order that keeps every XCD on ONE column slice of the gather table x [B][A] for a long
+// stretch: that slice (B * LPF * 16 bytes, 2 MiB at B = 4096 / LPF = 32) stays in the XCD's 4 MiB L2, so the k-fold row
+// gathers stop crossing the fabric (the row kernel re-fetches the 18.9 MB table ~96 times per step through the Infinity
+// Cache: 1.8 GB of fabric reads next to 1 GB of compulsory parameter / moment stream).  The encoder rows need no
+// row-wide reduction (no projection), so slices are independent; the bias element rides with slice 0.
+// Coefficients d a_bj are read in CSC order (coef[e], written that way by the decoder launch).  Same arithmetic per
+// element as the row kernel (entries accumulated in ascending row order, one rounding of the gradient, op-by-op Adam).
+template <int DT, int LPF, int EXTRA>
+__global__ __launch_bounds__(256) void fused_enc_sliced_kernel(
+    int D, int A, int units_per_slice, int total_units, const int32_t* __restrict__ col_ptr,
+    const int32_t* __restrict__ csc_row, const float* __restrict__ coef, const void* __restrict__ src,
+    const float* __restrict__ scale_p, void* __restrict__ W, void* __restrict__ m, void* __restrict__ v,
+    void* __restrict__ bias, void* __restrict__ m_b, void* __restrict__ v_b, AdamK k,
+    const int32_t* __restrict__ extra_row, const void* __restrict__ extra, const void* __restrict__ extra_bias) {
+    typedef DType<DT> D_;
+    typedef typename D_::T T;
+    constexpr int F = 64 / LPF;                    // features per wave
+    constexpr int U = 4;                           // gathered rows in flight per lane and pipeline stage
+    constexpr uint32_t OOB = 0x80000000u;          // buffer offset beyond every descriptor: the request returns zeros, no traffic
+    // workgroup b runs on XCD b % 8: unit = position in that XCD's contiguous range of the slice-major unit list
+    // (unit = one block of 4 * F features in one column slice)
+    const int per_xcd = (total_units + 7) >> 3;
+    const int u = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (u >= total_units) return;
+    const int slice = u / units_per_slice, fb = u - slice * units_per_slice;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane & (LPF - 1);
+    const int grp = lane & ~(LPF - 1);             // first lane of this feature's lane group
+    const int j = (fb * 4 + wave) * F + lane / LPF;
+    const bool jv = j < D;
+    const int col0 = (slice * LPF + sub) * 8;
+    const size_t off = (size_t)(jv ? j : 0) * A + col0;
+    // parameter / moment pieces first: they are in flight underneath the whole gather loop
+    Raw<DT> pw = zero_raw<DT>(), pm = zero_raw<DT>(), pv = zero_raw<DT>();
+    if (jv) { pw = load_raw_nt<DT>(W, off); pm = load_raw_nt<DT>(m, off); pv = load_raw_nt<DT>(v, off); }
+    const int s0 = jv ? col_ptr[j] : 0;
+    const int n = jv ? col_ptr[j + 1] - s0 : 0;
+    int nmax = n;
+#pragma unroll
+    for (int o = LPF; o < 64; o <<= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
+    nmax = __builtin_amdgcn_readfirstlane(nmax);
+    const rsrc_t rs = make_rsrc(src), rs_row = make_rsrc(csc_row), rs_coef = make_rsrc(coef);
+    const uint32_t row_bytes = (uint32_t)A * (uint32_t)sizeof(T), lane_off = (uint32_t)col0 * (uint32_t)sizeof(T);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float csum = 0.f;
+    // The entry lists are not read per entry: the LPF lanes of a feature fetch LPF of its (row, coefficient) pairs with
+    // one request each and hand them round through the LDS crossbar (ds_bpermute), which leaves ONE memory request per
+    // gathered row.  Groups of U rows are software-pipelined (group g + 1 in flight while group g is accumulated); every
+    // request is unconditional (entries past the feature's end: OOB) so the wait counts are exact.
+    // B, A < 2^24 (checked on the host).
+    for (int base = 0; base < nmax; base += LPF) {
+        const uint32_t eoff = base + sub < n ? (uint32_t)(s0 + base + sub) * 4u : OOB;
+        const int my_r = (int)__builtin_amdgcn_raw_buffer_load_b32(rs_row, eoff, 0, 0);
+        const float my_c = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_coef, eoff, 0, 0));
+        const int cnt = min(LPF, nmax - base);     // uniform
+        const int left = n - base;                 // entries of THIS feature from `base` on (may be <= 0)
+        Raw<DT> dr[2][U];
+        float c[2][U];
+        auto issue = [&](int i, Raw<DT> (&d_)[U], float (&c_)[U]) {
+#pragma unroll
+            for (int q = 0; q < U; ++q) {
+                const int src_lane = grp + ((i + q) & (LPF - 1));
+                const int rq = __shfl(my_r, src_lane, 64);
+                const float cq = __shfl(my_c, src_lane, 64);
+                const bool ok = i + q < left && i + q < LPF;
+                c_[q] = ok ? cq : 0.f;
+                d_[q] = load_raw_at<DT>(rs, 0u, ok ? __umul24((uint32_t)rq, row_bytes) + lane_off : OOB);
+            }
+        };
+        auto consume = [&](const Raw<DT> (&d_)[U], const float (&c_)[U]) {
+#pragma unroll
+            for (int q = 0; q < U; ++q) {
+                float x[8];
+                unpack(d_[q], x);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = fmaf(c_[q], x[e], acc[e]);
+                csum += c_[q];
+            }
+        };
+        issue(0, dr[0], c[0]);
+        for (int i = 0; i < cnt; i += 2 * U) {
+            issue(i + U, dr[1], c[1]);
+            consume(dr[0], c[0]);
+            issue(i + 2 * U, dr[0], c[0]);
+            if (i + U < cnt) consume(dr[1], c[1]);
+        }
+    }
+    if (!jv) return;
+    const float scale = scale_p ? *scale_p : 1.f;
+    float g[8], w[8], mm[8], vv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g[e] = D_::rnd(acc[e] * scale);          // the .grad a dense backward would hold
+    int xr = -1;
+    if constexpr (EXTRA != 0) {
+        xr = extra_row[j];
+        if (xr >= 0) {
+            float b[8];
+            load8<DT>(extra, (size_t)xr * A + col0, b);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) g[e] = D_::rnd(g[e] + b[e]);
+        }
+    }
+    unpack(pw, w); unpack(pm, mm); unpack(pv, vv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) adam_elem<DT>(w[e], g[e], mm[e], vv[e], k);
+    store8<DT>(W, off, w);
+    store8_nt<DT>(m, off, mm);
+    store8_nt<DT>(v, off, vv);
+    if (bias && slice == 0 && sub == 0) {
+        T* bp = reinterpret_cast<T*>(bias) + j; T* mp = reinterpret_cast<T*>(m_b) + j; T* vp = reinterpret_cast<T*>(v_b) + j;
+        float b = D_::ld(bp), mb = D_::ld(mp), vb = D_::ld(vp);
+        float gb = D_::rnd(scale * csum);
+        if constexpr (EXTRA != 0)
+            if (xr >= 0 && extra_bias) gb = D_::rnd(gb + D_::ld(reinterpret_cast<const T*>(extra_bias) + xr));
+        adam_elem<DT>(b, gb, mb, vb, k);
+        D_::st(bp, b); D_::st(mp, mb); D_::st(vp, vb);
+    }
+}
+
+static int g_sliced_mode = -1;     // 0 automatic, 1 never, 2 whenever the shape allows (tests)
+static int sliced_lpf(const mtc_desc* d, int A) {
+    if (g_sliced_mode < 0) {
+        const char* e = getenv("MTC_FUSED_SLICED");
+        g_sliced_mode = e ? atoi(e) : 0;
+        if (g_sliced_mode < 0 || g_sliced_mode > 2) g_sliced_mode = 0;
+    }
+    if (g_sliced_mode == 1 || d->dtype != MTC_BF16 || d->B >= (1 << 24)) return 0;     // (24-bit row-offset multiply)
+    // widest slice whose share of the gather table (B rows x LPF x 16 bytes) leaves room in a 4 MiB L2
+    for (int lpf = 32; lpf >= 8; lpf >>= 1) {
+        if (A % (lpf * 8)) continue;
+        const size_t table = (size_t)d->B * lpf * 16;
+        if (table <= (size_t)5 * 512 * 1024) {
+            // small problems (table already L2-sized as a whole) gain nothing: keep the row kernel
+            if (g_sliced_mode == 2 || (size_t)d->B * A * 2 > (size_t)6 * 1024 * 1024) return lpf;
+            return 0;
+        }
+    }
+    return 0;
+}
+
 static AdamK make_adam(const mtc_adam_hyper* h) {
     AdamK k;
     const double bc1 = 1.0 - pow(h->beta1, (double)h->step);
@@ -316,6 +463,13 @@ extern "C" int mtc_unitnorm_project(const mtc_desc* d, void* W_dec, void* grad, 
     return check_launch("mtc_unitnorm_project");
 }
 
+extern "C" int mtc_fused_set_sliced(int mode) {
+    if (mode < 0 || mode > 2) return -1;
+    const int prev = g_sliced_mode < 0 ? 0 : g_sliced_mode;
+    g_sliced_mode = mode;
+    return prev;
+}
+
 extern "C" int mtc_adam_flat(int32_t dtype, size_t n, void* p, const void* grad, void* m, void* v,
                              const mtc_adam_hyper* h_host, void* stream) {
     MTC_REQUIRE(p && grad && m && v && h_host, "mtc_adam_flat: null pointer");
@@ -335,7 +489,8 @@ extern "C" int mtc_adam_flat(int32_t dtype, size_t n, void* p, const void* grad,
 
 #define LAUNCH_FUSED_NC(DTV, COEF, PROJ, DOT, EX, NCV)                                                                          \
     hipLaunchKernelGGL((fused_grad_adam_kernel<DTV, COEF, NCV, PROJ, DOT, EX>), grid, block, 0, s, d->D, A, col_ptr, csc_row,      \
-                       csc_pos, coef, src, scale, W, m, v, bias, m_b, v_b, k, dv_out, l1_term, extra_row, extra, extra_bias)
+                       csc_pos, coef, src, scale, W, m, v, bias, m_b, v_b, k, dv_out, l1_term, extra_row, extra, extra_bias,          \
+                       csc_order)
 #define LAUNCH_FUSED(DTV, COEF, PROJ, DOT, EX)                                                                                    \
     do {                                                                                                                     \
         const int nc_ = nc_for(A);                                                                                           \
@@ -354,15 +509,16 @@ extern "C" int mtc_fused_backward_adam_dec(const mtc_desc* d, const int32_t* col
                                            void* W_dec, void* exp_avg, void* exp_avg_sq, const mtc_adam_hyper* h_host,
                                            float* d_vals_out, float l1_term, void* stream) {
     return mtc_fused_backward_adam_dec_extra(d, col_ptr, csc_row, csc_pos, vals, g, scale, W_dec, exp_avg, exp_avg_sq, h_host,
-                                             d_vals_out, l1_term, nullptr, nullptr, stream);
+                                             d_vals_out, l1_term, nullptr, nullptr, 0, stream);
 }
 
 extern "C" int mtc_fused_backward_adam_dec_extra(const mtc_desc* d, const int32_t* col_ptr, const int32_t* csc_row,
                                                  const int32_t* csc_pos, const void* vals, const void* g, const float* scale,
                                                  void* W_dec, void* exp_avg, void* exp_avg_sq, const mtc_adam_hyper* h_host,
                                                  float* d_vals_out, float l1_term, const int32_t* extra_row,
-                                                 const void* extra_rows, void* stream) {
+                                                 const void* extra_rows, int32_t d_vals_csc_order, void* stream) {
     if (check_desc(d, "mtc_fused_backward_adam_dec")) return -1;
+    const int csc_order = d_vals_csc_order ? 1 : 0;
     MTC_REQUIRE((extra_row == nullptr) == (extra_rows == nullptr), "mtc_fused_backward_adam_dec: extra_row and extra_rows go together");
     MTC_REQUIRE(col_ptr && csc_row && csc_pos && vals && g && W_dec && exp_avg && exp_avg_sq && h_host,
                 "mtc_fused_backward_adam_dec: null pointer");
@@ -393,7 +549,7 @@ extern "C" int mtc_fused_backward_adam_enc(const mtc_desc* d, const int32_t* col
                                            void* W_encT, void* exp_avg, void* exp_avg_sq, void* b_enc, void* b_exp_avg,
                                            void* b_exp_avg_sq, const mtc_adam_hyper* h_host, void* stream) {
     return mtc_fused_backward_adam_enc_extra(d, col_ptr, csc_row, csc_pos, d_vals, x_norm, scale, W_encT, exp_avg, exp_avg_sq,
-                                             b_enc, b_exp_avg, b_exp_avg_sq, h_host, nullptr, nullptr, nullptr, stream);
+                                             b_enc, b_exp_avg, b_exp_avg_sq, h_host, nullptr, nullptr, nullptr, 0, stream);
 }
 
 extern "C" int mtc_fused_backward_adam_enc_extra(const mtc_desc* d, const int32_t* col_ptr, const int32_t* csc_row,
@@ -401,8 +557,9 @@ extern "C" int mtc_fused_backward_adam_enc_extra(const mtc_desc* d, const int32_
                                                  const float* scale, void* W_encT, void* exp_avg, void* exp_avg_sq, void* b_enc,
                                                  void* b_exp_avg, void* b_exp_avg_sq, const mtc_adam_hyper* h_host,
                                                  const int32_t* extra_row, const void* extra_rows, const void* extra_bias_in,
-                                                 void* stream) {
+                                                 int32_t d_vals_csc_order, void* stream) {
     if (check_desc(d, "mtc_fused_backward_adam_enc")) return -1;
+    const int csc_order = d_vals_csc_order ? 1 : 0;
     MTC_REQUIRE((extra_row == nullptr) == (extra_rows == nullptr), "mtc_fused_backward_adam_enc: extra_row and extra_rows go together");
     MTC_REQUIRE(col_ptr && csc_row && csc_pos && d_vals && x_norm && W_encT && exp_avg && exp_avg_sq && b_enc && b_exp_avg &&
                 b_exp_avg_sq && h_host, "mtc_fused_backward_adam_enc: null pointer");
@@ -414,6 +571,21 @@ extern "C" int mtc_fused_backward_adam_enc_extra(const mtc_desc* d, const int32_
     void* W = W_encT; void* m = exp_avg; void* v = exp_avg_sq; void* bias = b_enc; void* m_b = b_exp_avg; void* v_b = b_exp_avg_sq;
     float* dv_out = nullptr; const float l1_term = 0.f;
     const void* extra = extra_rows; const void* extra_bias = extra_bias_in;
+    const int lpf = csc_order ? sliced_lpf(d, A) : 0;
+    if (lpf) {
+        // column-sliced walk: units = (slice, block of 4 waves x 64 / lpf features), slice-major, an eighth of the list per XCD
+        const int feats_per_block = 4 * (64 / lpf);
+        const int units_per_slice = (d->D + feats_per_block - 1) / feats_per_block;
+        const int total_units = units_per_slice * (A / (lpf * 8));
+        const dim3 grid(8 * ((total_units + 7) / 8)), block(256);
+#define LAUNCH_SLICED(LPFV, EX)                                                                                                  \
+        hipLaunchKernelGGL((fused_enc_sliced_kernel<MTC_BF16, LPFV, EX>), grid, block, 0, s, d->D, A, units_per_slice, total_units, \
+                           col_ptr, csc_row, d_vals, src, scale, W, m, v, bias, m_b, v_b, k, extra_row, extra, extra_bias)
+        if (extra_row) { if (lpf == 32) LAUNCH_SLICED(32, 1); else if (lpf == 16) LAUNCH_SLICED(16, 1); else LAUNCH_SLICED(8, 1); }
+        else { if (lpf == 32) LAUNCH_SLICED(32, 0); else if (lpf == 16) LAUNCH_SLICED(16, 0); else LAUNCH_SLICED(8, 0); }
+#undef LAUNCH_SLICED
+        return check_launch("mtc_fused_backward_adam_enc");
+    }
     if (extra_row) {
         if (d->dtype == MTC_BF16) LAUNCH_FUSED(MTC_BF16, MTC_F32, 0, 0, 1);
         else LAUNCH_FUSED(MTC_F32, MTC_F32, 0, 0, 1);

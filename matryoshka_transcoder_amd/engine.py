@@ -472,6 +472,7 @@ class HotPath:
         s = _stream()
         if h_enc.step != h_benc.step or h_enc.lr != h_benc.lr:
             raise _lib.MtcError("W_enc and b_enc must share one Adam step count / lr for the fused update")
+        row_map = E_dec = E_enc = e_b = None
         if extra is not None:
             row_map, E_dec, E_enc, e_b = extra
             _need(row_map, "extra row map", torch.int32, (self.D,))
@@ -479,23 +480,16 @@ class HotPath:
             _need(e_b, "extra bias elements", self.dtype)
             if dv_out is None or E_dec.shape[1] != self.A_t or E_enc.shape[1] != self.A_s or e_b.numel() != E_enc.shape[0]:
                 raise _lib.MtcError("extra gradient rows: pass d_vals=None and [n, A_t] / [n, A_s] / [n] operands")
-            check(self.lib.mtc_fused_backward_adam_dec_extra(
-                C.byref(d), _p(sel.col_ptr), _p(sel.csc_row), _p(sel.csc_pos), _p(sel.vals), _p(g), _p(scale), _p(W_dec),
-                _p(st_dec[0]), _p(st_dec[1]), C.byref(h_dec), _p(dv_out), float(l1_term), _p(row_map), _p(E_dec), s),
-                "mtc_fused_backward_adam_dec_extra")
-            check(self.lib.mtc_fused_backward_adam_enc_extra(
-                C.byref(d), _p(sel.col_ptr), _p(sel.csc_row), _p(sel.csc_pos), _p(d_vals), _p(x_norm), _p(scale), _p(W_encT),
-                _p(st_enc[0]), _p(st_enc[1]), _p(b_enc), _p(st_benc[0]), _p(st_benc[1]), C.byref(h_enc), _p(row_map),
-                _p(E_enc), _p(e_b), s), "mtc_fused_backward_adam_enc_extra")
-            return
-        check(self.lib.mtc_fused_backward_adam_dec(C.byref(d), _p(sel.col_ptr), _p(sel.csc_row), _p(sel.csc_pos), _p(sel.vals),
-                                                   _p(g), _p(scale), _p(W_dec), _p(st_dec[0]), _p(st_dec[1]), C.byref(h_dec),
-                                                   _p(dv_out), float(l1_term), s),
-              "mtc_fused_backward_adam_dec")
-        check(self.lib.mtc_fused_backward_adam_enc(C.byref(d), _p(sel.col_ptr), _p(sel.csc_row), _p(sel.csc_pos), _p(d_vals),
-                                                   _p(x_norm), _p(scale), _p(W_encT), _p(st_enc[0]), _p(st_enc[1]), _p(b_enc),
-                                                   _p(st_benc[0]), _p(st_benc[1]), C.byref(h_enc), s),
-              "mtc_fused_backward_adam_enc")
+        # d a_bj made by the decoder launch itself lives in CSC order (the order both launches walk; nothing else reads it)
+        csc_order = int(dv_out is not None)
+        check(self.lib.mtc_fused_backward_adam_dec_extra(
+            C.byref(d), _p(sel.col_ptr), _p(sel.csc_row), _p(sel.csc_pos), _p(sel.vals), _p(g), _p(scale), _p(W_dec),
+            _p(st_dec[0]), _p(st_dec[1]), C.byref(h_dec), _p(dv_out), float(l1_term), _p(row_map), _p(E_dec), csc_order, s),
+            "mtc_fused_backward_adam_dec_extra")
+        check(self.lib.mtc_fused_backward_adam_enc_extra(
+            C.byref(d), _p(sel.col_ptr), _p(sel.csc_row), _p(sel.csc_pos), _p(d_vals), _p(x_norm), _p(scale), _p(W_encT),
+            _p(st_enc[0]), _p(st_enc[1]), _p(b_enc), _p(st_benc[0]), _p(st_benc[1]), C.byref(h_enc), _p(row_map),
+            _p(E_enc), _p(e_b), csc_order, s), "mtc_fused_backward_adam_enc_extra")
 
     def colsum(self, d, g, scale=None):
         db_dec = torch.empty(self.A_t, dtype=self.dtype, device=g.device)
