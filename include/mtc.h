@@ -213,7 +213,9 @@ int mtc_reduce_scalars(const mtc_desc* d, const float* row_stats, const float* a
                        int32_t n_feat_total, float l1_coeff, float aux_penalty, float* scalars,
                        void* stream);
 
-/* a11  d a_bj = g_b . W_dec[j] (+ l1_coeff/(B*D)) for every selected entry, CSR order. */
+/* a11  d a_bj = round(g_b . W_dec[j]) (+ l1_coeff/(B*D), accumulated in the model dtype) for every selected entry, CSR
+ * order.  Rounded to the model dtype like the reference's autograd holds it (the output of g @ W_dec^T; a no-op for
+ * fp32 models), stored as float. */
 int mtc_decode_bwd_vals(const mtc_desc* d, const int32_t* row_ptr, const int32_t* col_idx,
                         const void* W_dec, const void* g, float l1_term, float* d_vals,
                         void* stream);

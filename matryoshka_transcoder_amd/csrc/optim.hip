@@ -276,8 +276,11 @@ __global__ __launch_bounds__(256, (DT == MTC_BF16 ? (NC <= 5 ? MTC_FUSED_WAVES :
 // row-wide reduction (no projection), so slices are independent; the bias element rides with slice 0.
 // Coefficients d a_bj are read in CSC order (coef[e], written that way by the decoder launch).  Same arithmetic per
 // element as the row kernel (entries accumulated in ascending row order, one rounding of the gradient, op-by-op Adam).
+#ifndef MTC_SLICED_U
+#define MTC_SLICED_U 2
+#endif
 template <int DT, int LPF, int EXTRA>
-__global__ __launch_bounds__(256) void fused_enc_sliced_kernel(
+__global__ __launch_bounds__(256, 8) void fused_enc_sliced_kernel(
     int D, int A, int units_per_slice, int total_units, const int32_t* __restrict__ col_ptr,
     const int32_t* __restrict__ csc_row, const float* __restrict__ coef, const void* __restrict__ src,
     const float* __restrict__ scale_p, void* __restrict__ W, void* __restrict__ m, void* __restrict__ v,
@@ -286,7 +289,11 @@ __global__ __launch_bounds__(256) void fused_enc_sliced_kernel(
     typedef DType<DT> D_;
     typedef typename D_::T T;
     constexpr int F = 64 / LPF;                    // features per wave
-    constexpr int U = 4;                           // gathered rows in flight per lane and pipeline stage
+    // A wave spends most of its life waiting on a chain of dependent reads (column pointers -> entry list -> rows ->
+    // parameter pieces): the launch is latency x occupancy bound, so registers are kept to 64 (8 waves per SIMD) and the
+    // pipeline stages small.  (Measured and dropped: walking several units per wave with the next unit's pointers and
+    // entry list requested behind the current unit's reads -- same time, more code.)
+    constexpr int U = MTC_SLICED_U;                // gathered rows in flight per lane and pipeline stage
     constexpr uint32_t OOB = 0x80000000u;          // buffer offset beyond every descriptor: the request returns zeros, no traffic
     // workgroup b runs on XCD b % 8: unit = position in that XCD's contiguous range of the slice-major unit list
     // (unit = one block of 4 * F features in one column slice)
@@ -301,9 +308,6 @@ __global__ __launch_bounds__(256) void fused_enc_sliced_kernel(
     const bool jv = j < D;
     const int col0 = (slice * LPF + sub) * 8;
     const size_t off = (size_t)(jv ? j : 0) * A + col0;
-    // parameter / moment pieces first: they are in flight underneath the whole gather loop
-    Raw<DT> pw = zero_raw<DT>(), pm = zero_raw<DT>(), pv = zero_raw<DT>();
-    if (jv) { pw = load_raw_nt<DT>(W, off); pm = load_raw_nt<DT>(m, off); pv = load_raw_nt<DT>(v, off); }
     const int s0 = jv ? col_ptr[j] : 0;
     const int n = jv ? col_ptr[j + 1] - s0 : 0;
     int nmax = n;
@@ -341,6 +345,10 @@ __global__ __launch_bounds__(256) void fused_enc_sliced_kernel(
         auto consume = [&](const Raw<DT> (&d_)[U], const float (&c_)[U]) {
 #pragma unroll
             for (int q = 0; q < U; ++q) {
+                // (Tried: the FMAs on the matrix pipe -- v_mfma_f32_4x4x4_16b_bf16 with A = c * identity gives every lane
+                // acc[i] += c * x[i] on its own packed values, 2 instructions instead of 12.  Bit-identical on small
+                // problems, but at 3.4e8 elements x 41 entries a few accumulators differ from fmaf in the last fp32 bit
+                // (the matrix pipe's adder is not a correctly rounded fused multiply-add), for a 2 % gain: dropped.)
                 float x[8];
                 unpack(d_[q], x);
 #pragma unroll
@@ -357,6 +365,9 @@ __global__ __launch_bounds__(256) void fused_enc_sliced_kernel(
         }
     }
     if (!jv) return;
+    // parameter / moment pieces AFTER the gather loop: a wave's memory reads return in order, so requesting them first
+    // would hold every gathered row (an L2 hit) behind three HBM round trips; other waves hide this latency instead
+    const Raw<DT> pw = load_raw_nt<DT>(W, off), pm = load_raw_nt<DT>(m, off), pv = load_raw_nt<DT>(v, off);
     const float scale = scale_p ? *scale_p : 1.f;
     float g[8], w[8], mm[8], vv[8];
 #pragma unroll

@@ -198,7 +198,17 @@ __device__ __forceinline__ void accumulate_run(const RowCtx<DT, NC>& rc, const v
     accumulate_run_u<DT, NC, gather_u(NC)>(rc, W, A, my_col, my_val, i0, n, acc);
 }
 
-// d_vals_out[i] = g . W[j_i] + l1_term for the `n` (<= 64) entries whose columns sit in my_col; g is
+// d loss / d a_bj as the reference's autograd holds it: the OUTPUT of a matmul in the model dtype (g @ W_dec^T, fp32
+// accumulation, one rounding), the l1 term accumulated onto it in that dtype -- no-ops for fp32 models.  With bf16 this
+// makes the reference's bf16 encoder gradients reproducible bit for bit (tests/golden/bf16_plain).
+template <int DT>
+__device__ __forceinline__ float dvals_round(float dot, float l1_term) {
+    float v = DType<DT>::rnd(dot);
+    if (l1_term != 0.f) v = DType<DT>::rnd(v + DType<DT>::rnd(l1_term));
+    return v;
+}
+
+// d_vals_out[i] = round(g . W[j_i]) (+ l1_term) for the `n` (<= 64) entries whose columns sit in my_col; g is
 // the row in storage form (model dtype, zero in chunks beyond the row).  Four rows at a time; the four
 // per-lane partials are folded with 7 cross-lane exchanges (halve the value set while halving the lane
 // set) instead of 4 x 6.
@@ -236,7 +246,7 @@ __device__ __forceinline__ void dot_run(const RowCtx<DT, NC>& rc, const void* __
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
         // entry index held by this lane's 16-lane group: 2*(lane>>5) + ((lane>>4)&1)
-        if ((lane & 15) == 0) d_vals_out[i + 2 * (lane >> 5) + ((lane >> 4) & 1)] = v + l1_term;
+        if ((lane & 15) == 0) d_vals_out[i + 2 * (lane >> 5) + ((lane >> 4) & 1)] = dvals_round<DT>(v, l1_term);
     }
     for (; i < n; ++i) {
         Raw<DT> r1[NC];
@@ -245,7 +255,7 @@ __device__ __forceinline__ void dot_run(const RowCtx<DT, NC>& rc, const void* __
 #pragma unroll
         for (int c = 0; c < NC; ++c) p = dot_chunk(g[c], r1[c], p);
         p = wave_sum(p);
-        if (lane == 0) d_vals_out[i] = p + l1_term;
+        if (lane == 0) d_vals_out[i] = dvals_round<DT>(p, l1_term);
     }
 }
 
@@ -308,7 +318,7 @@ __device__ __forceinline__ void accumulate_dot_run(const RowCtx<DT, NC>& rc, con
         for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
         const int e = i + 2 * (lane >> 5) + ((lane >> 4) & 1);
         const int pos = __shfl(my_pos, min(e, last), 64);
-        if ((lane & 15) == 0 && e < n) d_vals_out[pos] = v + l1_term;
+        if ((lane & 15) == 0 && e < n) d_vals_out[pos] = dvals_round<DT>(v, l1_term);
     }
 }
 

@@ -318,14 +318,18 @@ def backward(params, x_source, x_target, cfg, inter, grad_out: float = 1.0):
 
     db_dec = g_raw.sum(0)
     dW_dec = torch.zeros(D, A_t, dtype=F32).index_add(0, cols, vals[:, None] * g_raw[rows])
-    d_vals = (g_raw[rows] * Wd[cols]).sum(-1) + grad_out * cfg["l1_coeff"] / (B * D)
+    # d loss / d acts_topk is a matmul OUTPUT in the reference's autograd (g @ W_dec^T: fp32 accumulation, one rounding to
+    # the model dtype); the l1 term reaches it as a second gradient accumulated in that dtype (both no-ops for fp32)
+    d_vals = (g_raw[rows] * Wd[cols]).sum(-1).to(dt).to(F32)
+    if cfg["l1_coeff"]:
+        d_vals = (d_vals + torch.tensor(grad_out * cfg["l1_coeff"] / (B * D)).to(dt).to(F32)).to(dt).to(F32)
 
     d_pre_rows, d_pre_cols, d_pre_vals = rows, cols, d_vals
     if aux is not None:
         g_aux = g_aux * grad_out
         ar, ac, av = aux["rows"], aux["cols"], aux["vals"]
         dW_dec = dW_dec.index_add(0, ac, av[:, None] * g_aux[ar])
-        d_aux = (g_aux[ar] * Wd[ac]).sum(-1)
+        d_aux = (g_aux[ar] * Wd[ac]).sum(-1).to(dt).to(F32)
         d_pre_rows = torch.cat([rows, ar]); d_pre_cols = torch.cat([cols, ac])
         d_pre_vals = torch.cat([d_vals, d_aux])
 
