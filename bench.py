@@ -314,7 +314,7 @@ def main():
         }
         # stage -> (launches per step, kernel name in the committed PMC summary) for the stages priced below
         launches = {"encode": (1, "mtc::encode_bf16_mfma256p_kernel<false>"), "decode": (1, "mtc::decode_fwd_kernel<1, 5>"),
-                    "fused_backward_adam": (2, "mtc::fused_grad_adam_kernel<1, 1, 5, 1, 1, 0>")}
+                    "fused_backward_adam": (2, "mtc::fused_grad_adam_kernel<1, 1, 5, 1, 1, 0>")}     # (+ fused_enc_sliced_kernel)
         kernels = {}
         for n, t_ms in st.items():
             entry = {"ms": t_ms, "launches": launches.get(n, (None, None))[0]}

@@ -73,4 +73,9 @@ if os.path.exists("gpurun_out/pmc_enc/e_counter_collection.csv"):
                           "--reps 10 (config #2 operands, random data, back-to-back launches) and rocprofv3 --kernel-trace --stats "
                           "of the same program for the duration",
                "kernels": enc, "yardsticks": extra}, open(f"profiles/{tag}_encode_pmc.json", "w"), indent=1)
+for src, dst in ((f"gpurun_out/bench_aux_{tag}.json", f"profiles/{tag}_bench_aux_active.json"),
+                 (f"gpurun_out/fused_ab_{tag}.txt", f"profiles/{tag}_fused_ab.txt"),
+                 (f"gpurun_out/pmc_fused_{tag}.txt", f"profiles/{tag}_fused_pmc.txt")):
+    if os.path.exists(src):
+        shutil.copy(src, dst)
 print("profiles updated for", tag)

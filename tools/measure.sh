@@ -21,6 +21,10 @@ timeout -k 10 120 python -u tools/encode_only.py --blas > gpurun_out/enc_random.
 timeout -k 10 120 python -u tools/encode_only.py --zeros > gpurun_out/enc_zeros.json 2> gpurun_out/enc_zeros.err || exit 1
 timeout -k 10 120 python -u tools/encode_stamps.py > gpurun_out/enc_stamps.json 2> gpurun_out/enc_stamps.err || exit 1
 timeout -k 10 900 python -u tools/sweep.py > gpurun_out/sweep.log 2>&1 || { tail -5 gpurun_out/sweep.log; exit 1; }
+# the step with the auxiliary loss active (its products on mtc_gemm_nt), and the fused gradient + Adam launches A/B
+timeout -k 10 300 python -u bench.py --no-cpu-baseline --aux-active --steps 30 --warmup 3 > gpurun_out/bench_aux_$TAG.json 2> gpurun_out/bench_aux_$TAG.err || exit 1
+timeout -k 10 200 python -u tools/fused_ab.py > gpurun_out/fused_ab_$TAG.txt 2>&1 || exit 1
+bash tools/pmc_fused.sh > gpurun_out/pmc_fused_$TAG.txt 2>&1 || exit 1
 python3 - <<PY
 import json
 r = json.load(open("gpurun_out/bench_$TAG.json"))
