@@ -183,7 +183,8 @@ __global__ __launch_bounds__(256) void aux_fill_kernel(const void* __restrict__ 
 
 // wave per row: aux reconstruction, residual error, loss partial, gradient updates, d(aux acts)
 template <int DT, int NC>
-__global__ __launch_bounds__(256) void aux_fwd_kernel(int B, int A_t, int unit_norm, float coef_aux /* 2*aux_penalty/(B*A_t) */,
+__global__ __launch_bounds__(256) void aux_fwd_kernel(int B, int A_t, int unit_norm, float coef_aux /* fp32 aux_penalty/(B*A_t) */,
+                                                      float inv_n /* 1/(B*A_t) in the model dtype */,
                                                       const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col_idx,
                                                       const void* __restrict__ vals, const void* __restrict__ W_dec,
                                                       const void* __restrict__ x_target, const void* __restrict__ x_hat,
@@ -237,9 +238,13 @@ __global__ __launch_bounds__(256) void aux_fwd_kernel(int B, int A_t, int unit_n
             for (int k = 0; k < 8; ++k) {
                 const float e = D_::rnd(acc[c][k]) - (t[k] - h[k]);
                 sse = fmaf(e, e, sse);
-                ga[k] = coef_aux * e;
+                // fp32 branch of the loss (sae.py:336-341): d aux / d recon_aux = fl32(penalty / N) * 2 e; it reaches the
+                // model-dtype tensors rounded (the .float() casts' backward), and x_hat's gradient is the model-dtype SUM
+                // of its two consumers' gradients: round(g_post(l2) + round(ga)), then through the de-normalisation
+                ga[k] = D_::rnd(coef_aux * (2.f * e));
                 acc[c][k] = ga[k];                       // acc now holds g_aux for the second sweep
-                gg[k] += ga[k] * stdv;
+                float gp = D_::rnd(g_post_of<DT>(h[k], t[k], inv_n) + ga[k]);
+                gg[k] = unit_norm ? D_::rnd(gp * stdv) : gp;
             }
             if (g) store8<DT>(g, off, gg);
             if (g_aux) store8<DT>(g_aux, off, ga);
@@ -531,9 +536,10 @@ extern "C" int mtc_aux_fwd(const mtc_desc* d, const int32_t* row_ptr, const int3
     MTC_REQUIRE(row_ptr && col_idx && vals && W_dec && x_target && x_hat && aux_rows, "mtc_aux_fwd: null pointer");
     MTC_REQUIRE(!d->unit_norm || std, "mtc_aux_fwd: unit_norm needs std");
     MTC_REQUIRE(!d_aux_vals || g_aux, "mtc_aux_fwd: d_aux_vals needs g_aux");
-    const float coef_aux = (float)(2.0 * (double)aux_penalty / ((double)d->B * (double)d->A_t));
+    const float coef_aux = (float)((double)aux_penalty / ((double)d->B * (double)d->A_t));
+    const float inv_n = inv_n_in_dtype(d->dtype, (double)d->B * (double)d->A_t);
     DISPATCH_NC(d->dtype, nc_for(d->A_t), aux_fwd_kernel, dim3((d->B + 3) / 4), dim3(256), as_stream(stream), d->B, d->A_t,
-                d->unit_norm, coef_aux, row_ptr, col_idx, vals, W_dec, x_target, x_hat, std, g, g_aux, aux_rows, d_aux_vals,
+                d->unit_norm, coef_aux, inv_n, row_ptr, col_idx, vals, W_dec, x_target, x_hat, std, g, g_aux, aux_rows, d_aux_vals,
                 (const void*)nullptr, (const int32_t*)nullptr);
     return check_launch("mtc_aux_fwd");
 }
@@ -590,9 +596,10 @@ extern "C" int mtc_aux_residual(const mtc_desc* d, const void* x_hat_aux, const 
     if (check_desc(d, "mtc_aux_residual")) return -1;
     MTC_REQUIRE(x_hat_aux && x_target && x_hat && aux_rows, "mtc_aux_residual: null pointer");
     MTC_REQUIRE(!d->unit_norm || std, "mtc_aux_residual: unit_norm needs std");
-    const float coef_aux = (float)(2.0 * (double)aux_penalty / ((double)d->B * (double)d->A_t));
+    const float coef_aux = (float)((double)aux_penalty / ((double)d->B * (double)d->A_t));
+    const float inv_n = inv_n_in_dtype(d->dtype, (double)d->B * (double)d->A_t);
     DISPATCH_NC(d->dtype, nc_for(d->A_t), aux_fwd_kernel, dim3((d->B + 3) / 4), dim3(256), as_stream(stream), d->B, d->A_t,
-                d->unit_norm, coef_aux, (const int32_t*)nullptr, (const int32_t*)nullptr, (const void*)nullptr,
+                d->unit_norm, coef_aux, inv_n, (const int32_t*)nullptr, (const int32_t*)nullptr, (const void*)nullptr,
                 (const void*)nullptr, x_target, x_hat, std, g, g_aux, aux_rows, (float*)nullptr, x_hat_aux, active_dev);
     return check_launch("mtc_aux_residual");
 }

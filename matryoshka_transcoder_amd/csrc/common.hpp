@@ -128,6 +128,19 @@ template <> __device__ __forceinline__ uint32_t key_of<MTC_F32>(const void* acts
     return reinterpret_cast<const uint32_t*>(acts)[i];
 }
 
+// 1 / N as a scalar of the model dtype (host side): fp32, or bf16 with round-to-nearest-even
+inline float inv_n_in_dtype(int dtype, double n) {
+    const float f = (float)(1.0 / n);
+    if (dtype != MTC_BF16) return f;
+    uint32_t b;
+    __builtin_memcpy(&b, &f, 4);
+    b += 0x7fffu + ((b >> 16) & 1u);
+    b &= 0xffff0000u;
+    float r;
+    __builtin_memcpy(&r, &b, 4);
+    return r;
+}
+
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 }  // namespace mtc

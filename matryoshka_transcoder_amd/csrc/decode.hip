@@ -22,7 +22,7 @@ struct DecodeParams {
     int B, A_t, G;
     int prefix[MTC_MAX_PREFIX];
     int unit_norm;
-    float coef;            // 2 / (B * A_t)
+    float inv_n;           // 1 / (B * A_t) rounded to the model dtype (see g_post_of)
     float l1_term;         // l1_coeff / (B * D_total)
 };
 
@@ -114,7 +114,6 @@ __global__ __launch_bounds__(256, (NC <= 5 ? MTC_DECODE_WAVES : 2)) void decode_
     }
     // ---- last prefix: x_hat, sse, target moments, g
     float sse = 0.f, sx = 0.f, sxx = 0.f;
-    const float gscale = p.coef * (p.unit_norm ? stdv : 1.f);
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         if (rc.valid(c)) {
@@ -130,8 +129,9 @@ __global__ __launch_bounds__(256, (NC <= 5 ? MTC_DECODE_WAVES : 2)) void decode_
                 sse = fmaf(dlt, dlt, sse);
                 sx += t[k];
                 sxx = fmaf(t[k], t[k], sxx);
-                gg[k] = gscale * dlt;
-                acc[c][k] = D_::rnd(gg[k]);           // acc now holds g (as stored, in the model dtype) for the second sweep
+                gg[k] = g_post_of<DT>(v, t[k], p.inv_n);
+                if (p.unit_norm) gg[k] = D_::rnd(gg[k] * stdv);
+                acc[c][k] = gg[k];                    // acc now holds g (as stored, in the model dtype) for the second sweep
             }
             store8<DT>(x_hat, (size_t)row * p.A_t + rc.off(c), r);
             if (recons) store8<DT>(reinterpret_cast<T*>(recons) + ((size_t)(p.G - 1) * p.B + row) * p.A_t, rc.off(c), r);
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void decode_partial_kernel(DecodeParams p, con
 }
 
 // epilogue of the sharded path on the reduced partials of this rank's rows (one wave per row, no gather);
-// p.B = local rows, p.coef carries the GLOBAL batch
+// p.B = local rows, p.inv_n carries the GLOBAL batch
 template <int DT>
 __global__ __launch_bounds__(256) void decode_finish_kernel(DecodeParams p, const float* __restrict__ partial_last,
                                                             const void* __restrict__ partial_pre,
@@ -252,7 +252,6 @@ __global__ __launch_bounds__(256) void decode_finish_kernel(DecodeParams p, cons
         mean = D_::ld(reinterpret_cast<const T*>(mean_p) + row);
         stdv = D_::ld(reinterpret_cast<const T*>(std_p) + row);
     }
-    const float gscale = p.coef * (p.unit_norm ? stdv : 1.f);
     const int nch = p.A_t >> 3;
     float sx = 0.f, sxx = 0.f;
     for (int gi = 0; gi < p.G; ++gi) {
@@ -273,7 +272,8 @@ __global__ __launch_bounds__(256) void decode_finish_kernel(DecodeParams p, cons
                 r[k] = v;
                 const float dlt = v - t[k];
                 sse = fmaf(dlt, dlt, sse);
-                gg[k] = gscale * dlt;
+                gg[k] = g_post_of<DT>(v, t[k], p.inv_n);
+                if (p.unit_norm) gg[k] = D_::rnd(gg[k] * stdv);
                 if (last) { sx += t[k]; sxx = fmaf(t[k], t[k], sxx); }
             }
             if (recons) store8<DT>(reinterpret_cast<T*>(recons) + ((size_t)gi * p.B + row) * p.A_t, off, r);
@@ -350,7 +350,7 @@ static DecodeParams make_params(const mtc_desc* d, float l1_term) {
     for (int i = 0; i < MTC_MAX_PREFIX; ++i) p.prefix[i] = i < d->G ? d->prefix[i] : 0x7fffffff;
     p.prefix[d->G - 1] = 0x7fffffff;          // last group takes everything that is left
     p.unit_norm = d->unit_norm;
-    p.coef = (float)(2.0 / ((double)d->B * (double)d->A_t));
+    p.inv_n = inv_n_in_dtype(d->dtype, (double)d->B * (double)d->A_t);
     p.l1_term = l1_term;
     return p;
 }
@@ -407,7 +407,7 @@ extern "C" int mtc_decode_finish(const mtc_desc* d, int32_t B_total, const float
     MTC_REQUIRE(!d->unit_norm || (mean && std), "mtc_decode_finish: unit_norm needs mean/std");
     MTC_REQUIRE(B_total >= d->B, "mtc_decode_finish: B_total (%d) < local rows (%d)", B_total, d->B);
     DecodeParams p = make_params(d, 0.f);
-    p.coef = (float)(2.0 / ((double)B_total * (double)d->A_t));
+    p.inv_n = inv_n_in_dtype(d->dtype, (double)B_total * (double)d->A_t);
     if (d->dtype == MTC_BF16)
         hipLaunchKernelGGL(decode_finish_kernel<MTC_BF16>, dim3((d->B + 3) / 4), dim3(256), 0, as_stream(stream), p,
                            partial_last, partial_pre, b_dec, x_target, mean, std, x_hat, g, row_stats, recons);

@@ -208,6 +208,17 @@ __device__ __forceinline__ float dvals_round(float dot, float l1_term) {
     return v;
 }
 
+// dL/dx_hat of the l2 term as the reference's autograd forms it on model-dtype tensors (sae.py:236, training.py:172):
+//   d = round(x_post - x_t);  g_post = round(inv_n * (2 d))  with inv_n = 1 / (B A_t) ROUNDED to the model dtype (mean's
+//   backward divides a model-dtype tensor by N: for N not a power of two a bf16 run carries that 0.2 % scale);
+//   through the de-normalisation x_post = x_rec * std + mean:  g_rec = round(g_post * std).
+// Verified against torch's bf16 autograd: 100 % of the entries equal (the one-rounding form 2/N * d * std: ~60 %).
+template <int DT>
+__device__ __forceinline__ float g_post_of(float x_post, float x_t, float inv_n) {
+    const float d = DType<DT>::rnd(x_post - x_t);
+    return DType<DT>::rnd(inv_n * (2.f * d));
+}
+
 // d_vals_out[i] = round(g . W[j_i]) (+ l1_term) for the `n` (<= 64) entries whose columns sit in my_col; g is
 // the row in storage form (model dtype, zero in chunks beyond the row).  Four rows at a time; the four
 // per-lane partials are folded with 7 cross-lane exchanges (halve the value set while halving the lane

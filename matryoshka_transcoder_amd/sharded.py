@@ -346,13 +346,16 @@ class ShardedMatryoshkaTranscoder(MatryoshkaTranscoder):
         check(lib.mtc_decode_partial(C.byref(d1), _p(row_ptr), _p(col_idx), _p(vals), _p(W_dec), B, _p(part), _p(dummy), None, s),
               "mtc_decode_partial")
         comm.all_reduce(part)
-        # replicated: e = round(x_aux) - (x_t - x_hat); aux = penalty * mean(e^2); g_aux; g += g_aux * std_row
+        # replicated: e = round(x_aux) - (x_t - x_hat); aux = penalty * mean(e^2); the gradients in autograd's own rounding
+        # sequence on model-dtype tensors (see g_post_of in csrc/rowops.hpp): g_aux = round(fl32(penalty / N) * 2 e),
+        # g_post = round(round(inv_n * 2 round(x_hat - x_t)) + g_aux), g = round(g_post * std_row)
         e = part.to(self.dtype).float() - (x_target.float() - x_hat.float())
         aux_rows = (e * e).sum(1).contiguous()
-        ga32 = e * (2.0 * penalty / (B * A_t))
-        g_aux = ga32.to(self.dtype).contiguous()
-        std_row = self.x_std.reshape(-1, 1).float() if hp.unit_norm else 1.0
-        g.copy_((g.float() + ga32 * std_row).to(self.dtype))
+        n_elem = B * A_t
+        g_aux = (torch.tensor(penalty / n_elem, dtype=torch.float32, device=dev) * (2.0 * e)).to(self.dtype).contiguous()
+        inv_n = torch.tensor(1.0 / n_elem, dtype=torch.float32, device=dev).to(self.dtype)
+        g_post = inv_n * (2.0 * (x_hat - x_target)) + g_aux                    # every op rounds to the model dtype
+        g.copy_(g_post * self.x_std.reshape(-1, 1) if hp.unit_norm else g_post)
         d_aux = None
         if need_grad:
             d_aux = hp.decode_bwd_vals(d, asel, W_dec, g_aux, 0.0)

@@ -303,18 +303,24 @@ def backward(params, x_source, x_target, cfg, inter, grad_out: float = 1.0):
     x_hat = inter["recons"][-1].to(F32)
     xt = x_target.to(F32)
     rows, cols, vals = inter["rows"], inter["cols"].long(), inter["vals"].to(F32)
-    coef = 2.0 / (B * A_t)
-
-    g = coef * (x_hat - xt)
+    # dL/dx_hat exactly as autograd forms it on model-dtype tensors (checked against torch's bf16 autograd: every entry
+    # equal; a single rounding of 2/N * (x_hat - x_t) * std reproduces only ~60 % of them):
+    #   d = round(x_post - x_t); g_post = round(inv_n * 2 d), inv_n = 1/N as a model-dtype scalar (mean's backward);
+    #   aux active: x_post has a second consumer, the fp32 residual: its gradient fl32(penalty / N) * 2 e arrives
+    #   rounded (the .float() cast's backward) and the two are summed in the model dtype;
+    #   de-normalisation backward: g_rec = round(g_post * std)
+    rnd = lambda t: t.to(dt).to(F32)
+    n_elem = B * A_t
+    inv_n = rnd(torch.tensor(1.0 / n_elem, dtype=F32))
+    g = rnd(inv_n * (2.0 * rnd(x_hat - xt)))
     aux = inter["aux"]
+    g_aux = None
     if aux is not None:
-        g_aux = coef * cfg["aux_penalty"] * aux["e"]          # dL/d recon_aux ; residual not detached
-        g = g + g_aux
+        coef_aux = torch.tensor(cfg["aux_penalty"] / n_elem, dtype=F32)
+        g_aux = rnd(coef_aux * (2.0 * aux["e"]))              # dL/d recon_aux as the model-dtype matmul output receives it
+        g = rnd(g + g_aux)
     g = g * grad_out
-    g_raw = g * inter["std"].to(F32) if inter["std"] is not None else g
-    # the reference's autograd holds dL/dx_hat in the model dtype (x_hat is a dt tensor): one rounding here, which
-    # every gradient below inherits (a no-op for fp32 models)
-    g_raw = g_raw.to(dt).to(F32)
+    g_raw = rnd(g * inter["std"].to(F32)) if inter["std"] is not None else g
 
     db_dec = g_raw.sum(0)
     dW_dec = torch.zeros(D, A_t, dtype=F32).index_add(0, cols, vals[:, None] * g_raw[rows])

@@ -116,6 +116,13 @@ def check_against_oracle(cfg, params, cnt, xs, xt, res, hp):
     # a11
     grads = R.backward(params, xs, xt, cfg, inter)
     _close(res["g"], grads["g"], 1e-4 if f32 else 2e-2, 1e-7 if f32 else 1e-5, "g")
+    if not f32 and inter["aux"] is None:
+        # bf16: g follows autograd's rounding sequence (inv_n as a bf16 scalar, difference, product, de-normalisation each
+        # rounded), which the oracle reproduces bit for bit against the reference's fixtures -- so wherever the HIP
+        # reconstruction equals the oracle's (it differs only by the summation order of the gathered rows), g must be EQUAL
+        same = res["x_hat"].cpu() == inter["recons"][-1]
+        assert float(same.float().mean()) > 0.9
+        assert torch.equal(res["g"].cpu()[same], grads["g"].to(dt)[same]), "g differs where x_hat is identical"
     _close(res["d_vals"][:nnz], grads["d_vals"], 1e-4 if f32 else 2e-2, 1e-7 if f32 else 1e-5, "d_vals")
     dW_dec, dW_encT, db_enc, db_dec = res["grads"]
     rt, at = (1e-4, 1e-7) if f32 else (2e-2, 1e-4)
