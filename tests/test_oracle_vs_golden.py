@@ -207,6 +207,13 @@ def test_bf16_gradients_bit_exact_given_the_reference_tie_choice(name, monkeypat
     grads = R.backward(params, s0["x_source"], s0["x_target"], cfg, inter)
     for k in ("W_enc", "b_enc", "W_dec", "b_dec"):
         assert torch.equal(grads[k].to(torch.bfloat16), s0["grads"][k]), k
+    # and the whole first step: projected decoder gradient, updated parameters, both Adam moments -- bit for bit
+    opt = R.new_opt(params)
+    _, _, g2 = R.train_step(params, state, opt, s0["x_source"], s0["x_target"], cfg, lr=float(s0["lr"]))
+    assert torch.equal(g2["W_dec"], s0["W_dec_grad_projected"])
+    for k in ("W_enc", "b_enc", "W_dec", "b_dec"):
+        assert torch.equal(params[k], s0["params_after"][k]), k
+        assert torch.equal(opt["m"][k], s0["exp_avg"][k]) and torch.equal(opt["v"][k], s0["exp_avg_sq"][k]), k
 
 
 def test_prefix_helpers():
