@@ -175,6 +175,8 @@ def main():
     ap.add_argument("--unit-norm", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sharded", action="store_true", help="use the feature-sharded classes even on one GPU (overhead check)")
+    ap.add_argument("--comm", default="torch", choices=["torch", "libmtc"],
+                    help="transport of the sharded step's exchanges: torch.distributed (RCCL) or libmtc's own RCCL wrappers")
     ap.add_argument("--aux-active", action="store_true",
                     help="SURVEY 8d: the step with the auxiliary dead-feature loss active (every 7th feature forced dead: "
                          "tiny encoder column, counter preset); adds an `aux` block (its GEMMs on mtc_gemm_nt) to the line")
@@ -229,6 +231,8 @@ def main():
     A, D, k = cfg["act_size"], cfg["prefix_sizes"][-1], cfg["top_k"]
     if world > 1 or args.sharded:
         from matryoshka_transcoder_amd.sharded import ShardedMatryoshkaTranscoder, ShardedFusedAdam
+        if args.comm == "libmtc" and collective_backend == "nccl":
+            cfg["comm"] = "libmtc"
         tc = ShardedMatryoshkaTranscoder(cfg)
         opt = ShardedFusedAdam(tc, lr=cfg["lr"], betas=(cfg["beta1"], cfg["beta2"]))
     else:

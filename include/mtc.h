@@ -424,6 +424,29 @@ int mtc_collect_top_samples(int32_t dtype, int32_t n_rows, int32_t D, int32_t se
                             float* top_val, int32_t* top_slot, int32_t* slot_meta, int32_t* slot_ctx,
                             uint64_t* feat_count, float* feat_max, void* stream);
 
+/* SURVEY 8b / 8e  the exchanges of the feature-sharded step (no counterpart in the single-process reference; its
+ * multi-GPU layout is north_star's): thin wrappers over RCCL for hosts that do not use torch.distributed (the Python
+ * package does, matryoshka_transcoder_amd/sharded.py: per radix level a 16 KiB histogram all-reduce, the per-row tie-count
+ * all-gather, the reduce-scatter over batch rows of the partial reconstructions, the all-gather of the finished rows).
+ * One communicator per process and GPU, made on HIP's current device; RCCL is bound at run time (the copy already in
+ * the process, else librccl.so), so libmtc does not link against it.  Host side: the unique id is 128 bytes, made by
+ * rank 0 and handed to the others by the launcher.  All calls are asynchronous on `stream`; counts are in elements. */
+enum { MTC_COMM_F32 = 0, MTC_COMM_BF16 = 1, MTC_COMM_I32 = 2, MTC_COMM_U8 = 3, MTC_COMM_I64 = 4 };
+enum { MTC_COMM_SUM = 0, MTC_COMM_MAX = 1, MTC_COMM_MIN = 2 };
+#define MTC_COMM_ID_BYTES 128
+typedef struct mtc_comm mtc_comm;
+int mtc_comm_unique_id(void* id_host_128);
+int mtc_comm_init(mtc_comm** out, int32_t world, int32_t rank, const void* id_host_128);
+int mtc_comm_destroy(mtc_comm* c);
+int mtc_comm_world(const mtc_comm* c);
+int mtc_comm_rank(const mtc_comm* c);
+int mtc_comm_all_reduce(mtc_comm* c, const void* send, void* recv, size_t count, int32_t dtype, int32_t op, void* stream);
+/* recv [recv_count] = this rank's block of the element-wise reduction of every rank's send [world * recv_count] */
+int mtc_comm_reduce_scatter(mtc_comm* c, const void* send, void* recv, size_t recv_count, int32_t dtype, int32_t op,
+                            void* stream);
+/* recv [world * send_count] = every rank's send [send_count], in rank order */
+int mtc_comm_all_gather(mtc_comm* c, const void* send, void* recv, size_t send_count, int32_t dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

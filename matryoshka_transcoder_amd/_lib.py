@@ -75,6 +75,14 @@ PROTOTYPES = {
     "mtc_fused_backward_adam_dec_extra": (C.c_int, [DP, P, P, P, P, P, P, P, P, P, HP, P, C.c_float, P, P, C.c_int32, P]),
     "mtc_fused_backward_adam_enc_extra": (C.c_int, [DP, P, P, P, P, P, P, P, P, P, P, P, P, HP, P, P, P, C.c_int32, P]),
     "mtc_fused_set_sliced": (C.c_int, [C.c_int]),
+    "mtc_comm_unique_id": (C.c_int, [P]),
+    "mtc_comm_init": (C.c_int, [C.POINTER(P), C.c_int32, C.c_int32, P]),
+    "mtc_comm_destroy": (C.c_int, [P]),
+    "mtc_comm_world": (C.c_int, [P]),
+    "mtc_comm_rank": (C.c_int, [P]),
+    "mtc_comm_all_reduce": (C.c_int, [P, P, P, C.c_size_t, C.c_int32, C.c_int32, P]),
+    "mtc_comm_reduce_scatter": (C.c_int, [P, P, P, C.c_size_t, C.c_int32, C.c_int32, P]),
+    "mtc_comm_all_gather": (C.c_int, [P, P, P, C.c_size_t, C.c_int32, P]),
     "mtc_unitnorm_project": (C.c_int, [DP, P, P, P]),
     "mtc_aux_dead_list": (C.c_int, [DP, P, C.c_float, P, P, P, P, P]),
     "mtc_gemm_nt": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, P, C.c_int64, P, P, C.c_int64, P, C.c_int64, C.c_int32, P]),

@@ -140,6 +140,72 @@ class _Comm:
         return out.reshape((self.world,) + tuple(t.shape))
 
 
+class _LibComm:
+    """The same exchanges through libmtc's own RCCL wrappers (mtc_comm_*, include/mtc.h): ctypes calls on torch's current
+    stream, no torch.distributed on the data path (it only hands the 128-byte unique id round once).  Opt-in
+    (cfg["comm"] = "libmtc"): a collective then costs the host one ctypes call, which matters where the sharded step is
+    bound by the host's issue rate.  Same interface as _Comm."""
+    _DT = {torch.float32: 0, torch.bfloat16: 1, torch.int32: 2, torch.uint8: 3, torch.int64: 4}
+    _OP = {dist.ReduceOp.SUM: 0, dist.ReduceOp.MAX: 1, dist.ReduceOp.MIN: 2}
+    staged = False
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.lib = _lib.load()
+        uid = C.create_string_buffer(128)
+        if self.rank == 0:
+            check(self.lib.mtc_comm_unique_id(uid), "mtc_comm_unique_id")
+        box = [uid.raw]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        self._h = C.c_void_p()
+        check(self.lib.mtc_comm_init(C.byref(self._h), self.world, self.rank, C.create_string_buffer(box[0], 128)),
+              "mtc_comm_init")
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                self.lib.mtc_comm_destroy(h)
+            except Exception:  # noqa: BLE001  (interpreter shutdown)
+                pass
+
+    def _code(self, t):
+        try:
+            return self._DT[t.dtype]
+        except KeyError:
+            raise _lib.MtcError(f"mtc_comm: unsupported dtype {t.dtype}") from None
+
+    def all_reduce(self, t: torch.Tensor, op=dist.ReduceOp.SUM) -> torch.Tensor:
+        if not t.is_contiguous():
+            raise _lib.MtcError("mtc_comm: tensors must be contiguous")
+        check(self.lib.mtc_comm_all_reduce(self._h, _p(t), _p(t), t.numel(), self._code(t), self._OP[op], _stream()),
+              "mtc_comm_all_reduce")
+        return t
+
+    def reduce_scatter(self, t: torch.Tensor) -> torch.Tensor:
+        n = t.shape[0] // self.world
+        t = t.contiguous()
+        out = torch.empty((n,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        check(self.lib.mtc_comm_reduce_scatter(self._h, _p(t), _p(out), out.numel(), self._code(t), 0, _stream()),
+              "mtc_comm_reduce_scatter")
+        return out
+
+    def reduce_scatter_begin(self, t: torch.Tensor):
+        return (None, self.reduce_scatter(t), None)          # in stream order (no second stream here)
+
+    @staticmethod
+    def reduce_scatter_end(handle) -> torch.Tensor:
+        return handle[1]
+
+    def all_gather(self, t: torch.Tensor) -> torch.Tensor:
+        t = t.contiguous()
+        out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        check(self.lib.mtc_comm_all_gather(self._h, _p(t), _p(out), t.numel(), self._code(t), _stream()), "mtc_comm_all_gather")
+        return out
+
+
 class ShardedMatryoshkaTranscoder(MatryoshkaTranscoder):
     _overlap_ok = False        # one stream: the step is a chain of kernels and collectives
 
@@ -166,7 +232,7 @@ class ShardedMatryoshkaTranscoder(MatryoshkaTranscoder):
         self._hp = None
         self.to(cfg["device"])
         self._cnt = self._cnt.to(cfg["device"])
-        self.comm = _Comm(group)
+        self.comm = _LibComm(group) if cfg.get("comm") == "libmtc" else _Comm(group)
 
     def hot_path(self) -> HotPath:
         if self._hp is None or self._hp.dtype != self.dtype:

@@ -51,7 +51,7 @@ def _train(model, opt, batches, fused=False):
     return log
 
 
-def _worker(rank, world, port, dt_name, unit, fused, aux, ret, backend="gloo"):
+def _worker(rank, world, port, dt_name, unit, fused, aux, ret, backend="gloo", comm=None):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         torch.cuda.set_device(0)
@@ -62,6 +62,8 @@ def _worker(rank, world, port, dt_name, unit, fused, aux, ret, backend="gloo"):
         from matryoshka_transcoder_amd.sharded import ShardedFusedAdam, ShardedMatryoshkaTranscoder
         dt = getattr(torch, dt_name)
         cfg = _cfg(dt, unit, aux)
+        if comm:
+            cfg["comm"] = comm
         m = ShardedMatryoshkaTranscoder(cfg)
         opt = ShardedFusedAdam(m, lr=cfg["lr"], betas=(cfg["beta1"], cfg["beta2"]))
         log = _train(m, opt, _batches(dt, n=6 if aux else 3), fused)
@@ -144,12 +146,14 @@ def test_sharded_matches_single_gpu(dt_name, unit, fused, aux, gpu_lib):
             assert n_off <= 0.03 * v.numel() + 8, (k, n_off, v.numel())
 
 
-@pytest.mark.parametrize("dt_name,unit,aux", [("float32", False, False), ("bfloat16", True, "gemm")])
-def test_sharded_over_rccl_world1_matches_single_gpu(dt_name, unit, aux, gpu_lib):
+@pytest.mark.parametrize("dt_name,unit,aux,comm", [("float32", False, False, None), ("bfloat16", True, "gemm", None),
+                                                   ("bfloat16", True, "gemm", "libmtc"), ("float32", False, False, "libmtc")])
+def test_sharded_over_rccl_world1_matches_single_gpu(dt_name, unit, aux, comm, gpu_lib):
     """The transport bench.py uses at N > 1: RCCL through torch.distributed on device tensors (sharded._Comm without
     host staging: reduce_scatter_tensor / all_gather_into_tensor / all_reduce).  RCCL refuses two ranks on one GPU, so
     on the one-GPU test box the group has ONE rank; the exchanges are then identities and the fused step must
-    reproduce the single-GPU classes' losses."""
+    reproduce the single-GPU classes' losses.  comm = "libmtc": the same exchanges through libmtc's own RCCL wrappers
+    (mtc_comm_*, cfg["comm"] = "libmtc") instead of torch.distributed."""
     from matryoshka_transcoder_amd.training import FusedAdam
     from matryoshka_transcoder_amd.transcoder import MatryoshkaTranscoder
     dt = getattr(torch, dt_name)
@@ -161,7 +165,7 @@ def test_sharded_over_rccl_world1_matches_single_gpu(dt_name, unit, aux, gpu_lib
     torch.cuda.synchronize()
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
-    p = ctx.Process(target=_worker, args=(0, 1, _free_port(), dt_name, unit, True, aux, ret, "nccl"))
+    p = ctx.Process(target=_worker, args=(0, 1, _free_port(), dt_name, unit, True, aux, ret, "nccl", comm))
     p.start()
     p.join(170)
     assert ret.get(0) == "ok", ret.get(0)

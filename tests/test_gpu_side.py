@@ -257,3 +257,37 @@ def test_encode_at_activation_store_batch_size(gpu_lib):
         feats = tc.encode(x)
         assert int((feats != 0).sum()) == k * N
         assert float(tc.threshold) > 0
+
+
+def test_comm_wrappers_world1(gpu_lib):
+    """mtc_comm_* (the C ABI's RCCL steps) on a one-rank communicator: all-reduce / reduce-scatter /
+    all-gather through the library's run-time binding of the RCCL copy already in the process (PyTorch's)."""
+    import ctypes as C
+    from matryoshka_transcoder_amd import _lib
+    DEV = "cuda:0"
+    lib = gpu_lib
+    uid = (C.c_char * 128)()
+    _lib.check(lib.mtc_comm_unique_id(uid), "mtc_comm_unique_id")
+    comm = C.c_void_p()
+    _lib.check(lib.mtc_comm_init(C.byref(comm), 1, 0, uid), "mtc_comm_init")
+    try:
+        assert lib.mtc_comm_world(comm) == 1 and lib.mtc_comm_rank(comm) == 0
+        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        a = torch.arange(4096, dtype=torch.float32, device=DEV)
+        out = torch.zeros_like(a)
+        _lib.check(lib.mtc_comm_all_reduce(comm, C.c_void_p(a.data_ptr()), C.c_void_p(out.data_ptr()), a.numel(), 0, 0, s), "all_reduce")
+        h = torch.randint(0, 1000, (4096,), dtype=torch.int32, device=DEV)          # the select's histogram exchange
+        h2 = torch.zeros_like(h)
+        _lib.check(lib.mtc_comm_all_reduce(comm, C.c_void_p(h.data_ptr()), C.c_void_p(h2.data_ptr()), h.numel(), 2, 0, s), "all_reduce")
+        b = torch.randn(64, 32, device=DEV).to(torch.bfloat16)
+        rs = torch.zeros_like(b)
+        _lib.check(lib.mtc_comm_reduce_scatter(comm, C.c_void_p(b.data_ptr()), C.c_void_p(rs.data_ptr()), b.numel(), 1, 0, s), "reduce_scatter")
+        u = torch.randint(0, 255, (1000,), dtype=torch.uint8, device=DEV)           # the packed byte buffer of the finished rows
+        ag = torch.zeros_like(u)
+        _lib.check(lib.mtc_comm_all_gather(comm, C.c_void_p(u.data_ptr()), C.c_void_p(ag.data_ptr()), u.numel(), 3, s), "all_gather")
+        torch.cuda.synchronize()
+        assert torch.equal(out, a) and torch.equal(h2, h) and torch.equal(rs, b) and torch.equal(ag, u)
+        assert lib.mtc_comm_all_reduce(comm, C.c_void_p(a.data_ptr()), C.c_void_p(out.data_ptr()), 4, 99, 0, s) != 0
+        assert b"dtype" in lib.mtc_last_error()
+    finally:
+        _lib.check(lib.mtc_comm_destroy(comm), "mtc_comm_destroy")
