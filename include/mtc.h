@@ -140,6 +140,13 @@ int mtc_select_global_topk_carry(const mtc_desc* d, const void* acts, uint32_t k
                                  void* workspace, size_t workspace_bytes, uint32_t* carry,
                                  mtc_select_state* st, int32_t* row_ptr, int32_t* col_idx,
                                  void* vals, void* stream);
+/* The same with a5 folded in: threshold (the module's buffer, model dtype; NULL = leave it alone) receives the EMA update
+ * threshold <- (1 - ema_lr) threshold + ema_lr min(selected) (sae.py:349-361) inside the select's single-workgroup tail
+ * launch (per-row counts -> offsets -> next bound -> EMA are ONE launch here) instead of a mtc_threshold_ema launch. */
+int mtc_select_global_topk_carry_ema(const mtc_desc* d, const void* acts, uint32_t k_total,
+                                     void* workspace, size_t workspace_bytes, uint32_t* carry,
+                                     mtc_select_state* st, int32_t* row_ptr, int32_t* col_idx,
+                                     void* vals, void* threshold, float ema_lr, void* stream);
 
 /* Helpers of the feature-sharded caller (no counterpart in the single-process reference; each replaces a
  * handful of tiny tensor ops between two collectives):

@@ -52,6 +52,7 @@ PROTOTYPES = {
     "mtc_select_global_topk": (C.c_int, [DP, P, C.c_uint32, P, P, C.c_size_t, P, P, P, P, P]),
     "mtc_select_carry_workspace_bytes": (C.c_size_t, [DP]),
     "mtc_select_global_topk_carry": (C.c_int, [DP, P, C.c_uint32, P, C.c_size_t, P, P, P, P, P, P]),
+    "mtc_select_global_topk_carry_ema": (C.c_int, [DP, P, C.c_uint32, P, C.c_size_t, P, P, P, P, P, P, C.c_float, P]),
     "mtc_select_offsets_sharded": (C.c_int, [DP, P, P, C.c_int32, C.c_int32, C.c_int32, P, P, P, P, P]),
     "mtc_select_pack_minmax": (C.c_int, [P, P, P]),
     "mtc_threshold_ema_global": (C.c_int, [DP, P, P, C.c_float, P]),

@@ -264,11 +264,10 @@ __global__ __launch_bounds__(256) void select_rowsub_bf16_kernel(const void* __r
 }
 
 // one workgroup: global sub-bin totals -> tau / quota -> per-row (> tau, == tau)
-__global__ __launch_bounds__(1024) void select_finish_bf16_kernel(int B, mtc_select_state* st,
-                                                                  const uint32_t* __restrict__ row_above,
-                                                                  const uint32_t* __restrict__ row_sub,
-                                                                  const uint32_t* __restrict__ global_sub /* [8] or null */,
-                                                                  uint32_t* __restrict__ row_gt, uint32_t* __restrict__ row_eq) {
+__device__ __forceinline__ void select_finish_body(int B, mtc_select_state* st, const uint32_t* __restrict__ row_above,
+                                                   const uint32_t* __restrict__ row_sub,
+                                                   const uint32_t* __restrict__ global_sub /* [8] or null */,
+                                                   uint32_t* __restrict__ row_gt, uint32_t* __restrict__ row_eq) {
     __shared__ uint32_t sm[16][8];
     __shared__ uint32_t s_star;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -318,6 +317,13 @@ __global__ __launch_bounds__(1024) void select_finish_bf16_kernel(int B, mtc_sel
         row_gt[r] = gt; row_eq[r] = eq;
     }
 }
+__global__ __launch_bounds__(1024) void select_finish_bf16_kernel(int B, mtc_select_state* st,
+                                                                  const uint32_t* __restrict__ row_above,
+                                                                  const uint32_t* __restrict__ row_sub,
+                                                                  const uint32_t* __restrict__ global_sub,
+                                                                  uint32_t* __restrict__ row_gt, uint32_t* __restrict__ row_eq) {
+    select_finish_body(B, st, row_above, row_sub, global_sub, row_gt, row_eq);
+}
 
 // block-wide exclusive scan helper (1024 threads); returns exclusive prefix of v, total in *total
 __device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t* sm /*[16]*/, uint32_t* total) {
@@ -337,11 +343,11 @@ __device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t* s
     return wbase + inc - v;
 }
 
-__global__ __launch_bounds__(1024) void select_offsets_kernel(int B, const uint32_t* __restrict__ row_gt,
-                                                              const uint32_t* __restrict__ row_eq,
-                                                              const uint32_t* __restrict__ tie_before_in,
-                                                              mtc_select_state* st, int32_t* __restrict__ row_ptr,
-                                                              uint32_t* __restrict__ tie_take, uint32_t* carry) {
+__device__ __forceinline__ void select_offsets_body(int B, const uint32_t* __restrict__ row_gt,
+                                                    const uint32_t* __restrict__ row_eq,
+                                                    const uint32_t* __restrict__ tie_before_in, mtc_select_state* st,
+                                                    int32_t* __restrict__ row_ptr, uint32_t* __restrict__ tie_take,
+                                                    uint32_t* carry) {
     __shared__ uint32_t sm[16];
     const int t = threadIdx.x;
     const int per = (B + 1023) / 1024;
@@ -382,6 +388,13 @@ __global__ __launch_bounds__(1024) void select_offsets_kernel(int B, const uint3
             carry[0] = g;
         }
     }
+}
+__global__ __launch_bounds__(1024) void select_offsets_kernel(int B, const uint32_t* __restrict__ row_gt,
+                                                              const uint32_t* __restrict__ row_eq,
+                                                              const uint32_t* __restrict__ tie_before_in,
+                                                              mtc_select_state* st, int32_t* __restrict__ row_ptr,
+                                                              uint32_t* __restrict__ tie_take, uint32_t* carry) {
+    select_offsets_body(B, row_gt, row_eq, tie_before_in, st, row_ptr, tie_take, carry);
 }
 
 // wave per row: ordered compaction of the selected entries
@@ -744,6 +757,39 @@ __global__ __launch_bounds__(1024) void nnz_abs_kernel(int B, const float* __res
 }
 
 template <int DT>
+__device__ __forceinline__ void threshold_ema_body(const mtc_select_state* st, void* threshold, float lr) {
+    typedef DType<DT> D_;
+    typedef typename D_::T T;
+    if (st->nnz == 0 || st->min_sel_bits == 0xffffffffu) return;     // "if positive_mask.any()"
+    T* p = reinterpret_cast<T*>(threshold);
+    const float thr = D_::ld(p);
+    const float mn = __uint_as_float(st->min_sel_bits);
+    const float a = D_::rnd((float)(1.0 - (double)lr) * thr);
+    const float b = D_::rnd(lr * mn);
+    D_::st(p, D_::rnd(a + b));
+}
+
+// The single-workgroup tail of the carried-bound select as ONE launch: [bf16: sub-bin totals -> tau / quota -> per-row
+// counts] -> CSR offsets, tie quota, next step's bound -> [threshold EMA, sae.py:349-361, when the buffer is given].
+// The pieces run back to back in the same 1024 threads; each piece's global results are read by the next after a
+// barrier (one workgroup: its own writes are visible to it).
+template <int DT>
+__global__ __launch_bounds__(1024) void select_tail_kernel(int B, mtc_select_state* st, int with_finish,
+                                                           const uint32_t* __restrict__ row_above,
+                                                           const uint32_t* __restrict__ row_sub, uint32_t* row_gt,
+                                                           uint32_t* row_eq, int32_t* __restrict__ row_ptr,
+                                                           uint32_t* __restrict__ tie_take, uint32_t* carry, void* threshold,
+                                                           float lr) {
+    if (with_finish) {
+        select_finish_body(B, st, row_above, row_sub, nullptr, row_gt, row_eq);
+        __threadfence_block();
+        __syncthreads();
+    }
+    select_offsets_body(B, row_gt, row_eq, nullptr, st, row_ptr, tie_take, carry);
+    if (threshold && threadIdx.x == 0) threshold_ema_body<DT>(st, threshold, lr);     // thread 0 wrote st->nnz / min_sel_bits itself
+}
+
+template <int DT>
 __global__ void threshold_ema_kernel(const mtc_select_state* __restrict__ st, void* threshold, float lr) {
     typedef DType<DT> D_;
     typedef typename D_::T T;
@@ -955,6 +1001,14 @@ extern "C" size_t mtc_select_carry_workspace_bytes(const mtc_desc* d) {
 extern "C" int mtc_select_global_topk_carry(const mtc_desc* d, const void* acts, uint32_t k_total, void* workspace,
                                             size_t workspace_bytes, uint32_t* carry, mtc_select_state* st,
                                             int32_t* row_ptr, int32_t* col_idx, void* vals, void* stream) {
+    return mtc_select_global_topk_carry_ema(d, acts, k_total, workspace, workspace_bytes, carry, st, row_ptr, col_idx, vals,
+                                            nullptr, 0.f, stream);
+}
+
+extern "C" int mtc_select_global_topk_carry_ema(const mtc_desc* d, const void* acts, uint32_t k_total, void* workspace,
+                                                size_t workspace_bytes, uint32_t* carry, mtc_select_state* st,
+                                                int32_t* row_ptr, int32_t* col_idx, void* vals, void* threshold,
+                                                float ema_lr, void* stream) {
     if (check_desc(d, "mtc_select_global_topk_carry")) return -1;
     MTC_REQUIRE(acts && workspace && carry && st && row_ptr && col_idx && vals, "mtc_select_global_topk_carry: null pointer");
     MTC_REQUIRE(workspace_bytes >= mtc_select_carry_workspace_bytes(d),
@@ -988,7 +1042,6 @@ extern "C" int mtc_select_global_topk_carry(const mtc_desc* d, const void* acts,
         if ((rc = hist_impl(d, C, cand_vals, 0, st, hist, flag, 1, stream, acts, d->D))) return rc;
         if ((rc = mtc_select_scan(d, 0, hist, st, stream))) return rc;
         if ((rc = rowsub_impl(d, C, cand_vals, st, row_above, row_sub, flag, 1, stream, acts, d->D))) return rc;
-        if ((rc = mtc_select_finish_rows(d, st, row_above, row_sub, nullptr, row_gt, row_eq, stream))) return rc;
     } else {
         const int levels = mtc_select_levels(d);
         for (int l = 0; l < levels; ++l) {
@@ -997,7 +1050,12 @@ extern "C" int mtc_select_global_topk_carry(const mtc_desc* d, const void* acts,
         }
         if ((rc = count_impl(d, C, cand_vals, st, nullptr, row_gt, row_eq, flag, 1, stream, acts, d->D))) return rc;
     }
-    if ((rc = offsets_impl(d, row_gt, row_eq, nullptr, st, row_ptr, tie_take, carry, stream))) return rc;
+    // one launch: [bf16: finish] + offsets + next bound + [threshold EMA].  With a tau the smallest selected value is tau,
+    // noted by the offsets piece; without one (fewer positives than k) the rowsub / count pass noted it -- either way
+    // st->min_sel_bits is final before the fill, which does not touch it in TopK mode
+    DISPATCH_DT(d->dtype, select_tail_kernel, dim3(1), dim3(1024), 0, s, d->B, st, d->dtype == MTC_BF16 ? 1 : 0,
+                (const uint32_t*)row_above, (const uint32_t*)row_sub, row_gt, row_eq, row_ptr, tie_take, carry, threshold, ema_lr);
+    if ((rc = check_launch("mtc_select_global_topk_carry"))) return rc;
     return fill_impl(d, C, cand_vals, st, nullptr, row_ptr, tie_take, col_idx, vals, cand_cols, flag, 1, stream, acts, d->D);
 }
 

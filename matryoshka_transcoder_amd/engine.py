@@ -150,9 +150,10 @@ class HotPath:
             self._carry[key] = torch.zeros(8, dtype=torch.int32, device=device)
         return self._carry[key]
 
-    def select_topk(self, d, acts, k_total: int, carry: bool = False) -> Selection:
+    def select_topk(self, d, acts, k_total: int, carry: bool = False, threshold=None, ema_lr: float = 0.01) -> Selection:
         """Global batch-TopK.  carry=True (training loop): use / refresh the lower bound of tau carried from
-        the previous call on this device (identical result, one pass over acts instead of three)."""
+        the previous call on this device (identical result, one pass over acts instead of three); `threshold` (the
+        module's buffer) then also receives its EMA update (a5) inside the select's tail launch."""
         dev = acts.device
         st = torch.empty(16, dtype=torch.int32, device=dev)
         row_ptr = torch.empty(d.B + 1, dtype=torch.int32, device=dev)
@@ -162,9 +163,12 @@ class HotPath:
         if carry:
             ws_bytes = self.lib.mtc_select_carry_workspace_bytes(C.byref(d))
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-            check(self.lib.mtc_select_global_topk_carry(C.byref(d), _p(acts), int(k_total), _p(ws), ws_bytes,
-                                                        _p(self.carry_state(dev)), _p(st), _p(row_ptr), _p(col_idx),
-                                                        _p(vals), _stream()), "mtc_select_global_topk_carry")
+            if threshold is not None:
+                _need(threshold, "threshold", self.dtype)
+            check(self.lib.mtc_select_global_topk_carry_ema(C.byref(d), _p(acts), int(k_total), _p(ws), ws_bytes,
+                                                            _p(self.carry_state(dev)), _p(st), _p(row_ptr), _p(col_idx),
+                                                            _p(vals), _p(threshold), float(ema_lr), _stream()),
+                  "mtc_select_global_topk_carry")
             return Selection(st, row_ptr, col_idx, vals)
         ws_bytes = self.lib.mtc_select_workspace_bytes(C.byref(d))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)

@@ -215,8 +215,8 @@ class MatryoshkaTranscoder(nn.Module):
     # ------------------------------------------------------------------ the fused chain
     def _select(self, hp, d, acts, training: bool) -> Selection:
         if training:
-            sel = hp.select_topk(d, acts, int(self.config["top_k"]) * d.B, carry=True)
-            hp.threshold_ema(d, sel, self.threshold)
+            # threshold EMA (a5) rides in the select's tail launch
+            sel = hp.select_topk(d, acts, int(self.config["top_k"]) * d.B, carry=True, threshold=self.threshold)
         else:
             sel = hp.select_threshold(d, acts, self.threshold)
         return sel
