@@ -374,7 +374,7 @@ int mtc_aux_fwd(const mtc_desc* d, const int32_t* row_ptr, const int32_t* col_id
 /* a9, dense (GEMM) form -- what the reference itself computes (sae.py:332-341: acts_aux @ W_dec[dead]).  With
  * n_dead dead features the aux branch is four GEMMs over the compacted dead set ([B, n_dead] x [n_dead, A]); for
  * every n_dead <= D these cost less on MFMA than gathering k_aux decoder rows per batch row (B*k_aux*A*s bytes).
- * libmtc provides the selection and the fused elementwise parts, the caller runs the plain GEMMs (hipBLASLt):
+ * libmtc provides the selection, the fused elementwise parts and the products themselves (mtc_gemm_nt above):
  *   mtc_aux_dense_fill : acts_aux[B][n_pad] (model dtype) = the row's top-k_aux dead activations in dead-list
  *                        column order (threshold / tie quota from mtc_aux_select), zeros elsewhere and in the padding;
  *   mtc_aux_residual   : given x_hat_aux = acts_aux @ W_dec[dead]: e = x_hat_aux - (x_target - x_hat) (residual not
@@ -383,6 +383,13 @@ int mtc_aux_fwd(const mtc_desc* d, const int32_t* row_ptr, const int32_t* col_id
 int mtc_aux_dense_fill(const mtc_desc* d, const void* acts, const int32_t* dead_idx, const int32_t* n_dead_dev,
                        const uint32_t* row_tau_bits, const uint32_t* row_tie_quota, int32_t n_pad, void* acts_aux,
                        void* stream);
+/* mtc_aux_select + mtc_aux_dense_fill in ONE pass over the activations (sae.py:332-336: the top-k_aux of the dead
+ * columns scattered into a dense acts_aux): a workgroup per batch row holds the row's dead columns in LDS, so the
+ * activations are gathered once instead of three times.  Same row_cnt / row_tau_bits / row_tie_quota / acts_aux as the
+ * two calls (which it falls back to when n_pad * element size exceeds 40 KB or the rows do not take 8-byte stores). */
+int mtc_aux_select_dense(const mtc_desc* d, const void* acts, const int32_t* dead_idx, const int32_t* n_dead_dev,
+                         int32_t top_k_aux, int32_t n_pad, uint32_t* row_cnt, uint32_t* row_tau_bits,
+                         uint32_t* row_tie_quota, void* acts_aux, void* stream);
 int mtc_aux_residual(const mtc_desc* d, const void* x_hat_aux, const void* x_target, const void* x_hat, const void* std,
                      float aux_penalty, void* g, void* g_aux, float* aux_rows,
                      const int32_t* active_dev /* optional device int32: 0 = no dead feature after all (sae.py:331): aux_rows

@@ -94,6 +94,7 @@ PROTOTYPES = {
     "mtc_aux_fill": (C.c_int, [DP, P, P, P, P, P, P, P, P, P]),
     "mtc_aux_fwd": (C.c_int, [DP, P, P, P, P, P, P, P, C.c_float, P, P, P, P, P]),
     "mtc_aux_dense_fill": (C.c_int, [DP, P, P, P, P, P, C.c_int32, P, P]),
+    "mtc_aux_select_dense": (C.c_int, [DP, P, P, P, C.c_int32, C.c_int32, P, P, P, P, P]),
     "mtc_aux_residual": (C.c_int, [DP, P, P, P, P, C.c_float, P, P, P, P, P]),
     "mtc_aux_mask": (C.c_int, [C.c_int32, C.c_uint64, P, P, P]),
     "mtc_aux_row_candidates": (C.c_int, [DP, P, P, P, P, P, C.c_int32, P, P]),

@@ -27,12 +27,17 @@ __global__ __launch_bounds__(1024) void dead_list_kernel(int D, const float* __r
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int chunks = (D + 1023) / 1024;
     uint32_t near = 0;
-    for (int c = 0; c < chunks; ++c) {
-        const int j = c * 1024 + t;
-        const float v = j < D ? cnt[j] : -1.f;
-        near += v >= n_to_dead - 1.f ? 1u : 0u;  // a counter grows by at most 1 per forward: the next list's length bound
-        const uint64_t b = __ballot(v >= n_to_dead);
-        if (lane == 0) wc[c * 16 + w] = (uint32_t)__popcll(b);
+    for (int c0 = 0; c0 < chunks; c0 += 8) {          // 8 chunks' reads in flight (one workgroup: nothing else hides the latency)
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int j = (c0 + u) * 1024 + t; v[u] = j < D ? cnt[j] : -1.f; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (c0 + u >= chunks) break;
+            near += v[u] >= n_to_dead - 1.f ? 1u : 0u;  // a counter grows by at most 1 per forward: the next list's length bound
+            const uint64_t b = __ballot(v[u] >= n_to_dead);
+            if (lane == 0) wc[(c0 + u) * 16 + w] = (uint32_t)__popcll(b);
+        }
     }
     near = wave_sum_u32(near);
     if (lane == 0) sm_near[w] = near;
@@ -52,14 +57,22 @@ __global__ __launch_bounds__(1024) void dead_list_kernel(int D, const float* __r
     }
     __syncthreads();
     const uint32_t total = s_total;
-    for (int c = 0; c < chunks; ++c) {
-        const int j = c * 1024 + t;
-        const bool dead = j < D && cnt[j] >= n_to_dead;
-        const uint64_t b = __ballot(dead);
-        const uint32_t pos = wc[c * 16 + w] + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
-        if (j < D) {
-            if (row_map) row_map[j] = dead ? (int32_t)pos : -1;
-            if (dead) dead_idx[pos] = j;
+    for (int c0 = 0; c0 < chunks; c0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int j = (c0 + u) * 1024 + t; v[u] = j < D ? cnt[j] : -1.f; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = c0 + u;
+            if (c >= chunks) break;
+            const int j = c * 1024 + t;
+            const bool dead = v[u] >= n_to_dead;       // (j >= D reads as -1: never dead)
+            const uint64_t b = __ballot(dead);
+            const uint32_t pos = wc[c * 16 + w] + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+            if (j < D) {
+                if (row_map) row_map[j] = dead ? (int32_t)pos : -1;
+                if (dead) dead_idx[pos] = j;
+            }
         }
     }
     // the tail of the list holds a valid feature (0): callers that size their launches from an upper bound of the
@@ -282,20 +295,225 @@ __global__ __launch_bounds__(256) void aux_dense_fill_kernel(const void* __restr
     const size_t base = (size_t)row * D;
     T* o = reinterpret_cast<T*>(out) + (size_t)row * n_pad;
     uint32_t ties_seen = 0;
-    for (int i0 = 0; i0 < n_pad; i0 += 64) {
-        const int i = i0 + lane;
-        uint32_t k = 0; T raw = 0;
-        if (i < n_dead) { const int col = dead_idx[i]; raw = reinterpret_cast<const T*>(acts)[base + col]; k = key_of<DT>(acts, base + col); }
-        const bool ok = k != 0 && k <= 0x7f800000u;
-        const bool eq = ok && quota && k == tau;
-        bool sel = ok && k > tau;
-        const uint64_t eqb = __ballot(eq);
-        if (eqb) {
-            const uint32_t rank = ties_seen + (uint32_t)__popcll(eqb & ((1ull << lane) - 1ull));
-            if (eq && rank < quota) sel = true;
-            ties_seen += (uint32_t)__popcll(eqb);
+    // four 64-column groups per trip: their index and activation reads are requested together (the two dependent reads
+    // of a group would otherwise cost a full round trip per 64 columns); the groups are then examined in column order
+    for (int i0 = 0; i0 < n_pad; i0 += 256) {
+        int col[4];
+        T raw[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = i0 + 64 * u + lane; col[u] = i < n_dead ? dead_idx[i] : -1; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) raw[u] = col[u] >= 0 ? reinterpret_cast<const T*>(acts)[base + col[u]] : (T)0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + 64 * u + lane;
+            if (i0 + 64 * u >= n_pad) break;             // uniform
+            uint32_t k = 0;
+            if (col[u] >= 0) {
+                if constexpr (DT == MTC_BF16) k = (uint32_t)raw[u] << 16;
+                else k = __float_as_uint(raw[u]);
+            }
+            const bool ok = k != 0 && k <= 0x7f800000u;
+            const bool eq = ok && quota && k == tau;
+            bool sel = ok && k > tau;
+            const uint64_t eqb = __ballot(eq);
+            if (eqb) {
+                const uint32_t rank = ties_seen + (uint32_t)__popcll(eqb & ((1ull << lane) - 1ull));
+                if (eq && rank < quota) sel = true;
+                ties_seen += (uint32_t)__popcll(eqb);
+            }
+            if (i < n_pad) o[i] = sel ? raw[u] : (T)0;
         }
-        if (i < n_pad) o[i] = sel ? raw : (T)0;
+    }
+}
+
+// aux_select + aux_dense_fill in ONE pass over the activations: one workgroup per batch row gathers the row's dead
+// columns ONCE into LDS (raw bits; the two-launch form reads them three times: two radix levels + the fill), runs the
+// radix levels on the LDS copy, resolves the tie quota in dead-list order and writes the dense row with 8-byte stores.
+// Same threshold / quota / selection as the two kernels above (tests compare them bit for bit).
+//   LDS: hist 16 KB + keys n_pad * sizeof(T) (dynamic)
+template <int DT>
+__global__ __launch_bounds__(256) void aux_select_dense_kernel(const void* __restrict__ acts, int D, int n_pad,
+                                                               const int32_t* __restrict__ dead_idx,
+                                                               const int32_t* __restrict__ n_dead_p, int k_aux_max,
+                                                               uint32_t* __restrict__ row_cnt, uint32_t* __restrict__ row_tau,
+                                                               uint32_t* __restrict__ row_quota, void* __restrict__ out) {
+    typedef typename DType<DT>::T T;
+    constexpr int EPD = 4 / (int)sizeof(T);                  // elements per dword
+    extern __shared__ __align__(16) uint32_t kw[];           // [n_pad / EPD] raw bits of the row's dead columns (0 beyond n_dead)
+    __shared__ uint32_t hist[4096];
+    __shared__ uint32_t wtot[4];
+    __shared__ uint32_t s_bin, s_above, s_h, s_cut;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int row = blockIdx.x;
+    const int n_dead = min(*n_dead_p, n_pad);
+    const uint32_t k_aux = (uint32_t)min(k_aux_max, n_dead);
+    const int nw = n_pad / EPD;                               // host: n_pad % (2 EPD) == 0
+    uint2* o2 = reinterpret_cast<uint2*>(reinterpret_cast<T*>(out) + (size_t)row * n_pad);
+    if (n_dead == 0 || k_aux == 0) {
+        for (int w = 2 * t; w < nw; w += 512) o2[w >> 1] = make_uint2(0u, 0u);
+        if (t == 0) { row_cnt[row] = 0; row_tau[row] = 0; row_quota[row] = 0; }
+        return;
+    }
+    const T* a = reinterpret_cast<const T*>(acts) + (size_t)row * D;
+    auto key_bits = [](uint32_t word, int e) -> uint32_t {   // radix key of element e of a dword
+        if constexpr (DT == MTC_BF16) return ((word >> (16 * e)) & 0xffffu) << 16;
+        else return word;
+    };
+    for (int i = t; i < 4096; i += 256) hist[i] = 0;
+    if (t == 0) { s_bin = 0xffffffffu; s_above = 0; s_h = 0; s_cut = 0xffffffffu; }
+    __syncthreads();
+    // ---- gather the row's dead columns (4 dwords per thread in flight), level-0 histogram on the way
+    for (int w0 = t; w0 < nw; w0 += 1024) {
+        int col[4][EPD];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int w = w0 + 256 * u;
+#pragma unroll
+            for (int e = 0; e < EPD; ++e) col[u][e] = -1;
+            if (w < nw) {
+                if constexpr (EPD == 2) {
+                    const int2 c2 = reinterpret_cast<const int2*>(dead_idx)[w];   // the list's tail is gatherable (feature 0)
+                    col[u][0] = 2 * w < n_dead ? c2.x : -1;
+                    col[u][1] = 2 * w + 1 < n_dead ? c2.y : -1;
+                } else {
+                    col[u][0] = w < n_dead ? dead_idx[w] : -1;
+                }
+            }
+        }
+        uint32_t word[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if constexpr (EPD == 2) {
+                const uint32_t lo = col[u][0] >= 0 ? (uint32_t)a[col[u][0]] : 0u;
+                const uint32_t hi = col[u][1] >= 0 ? (uint32_t)a[col[u][1]] : 0u;
+                word[u] = lo | (hi << 16);
+            } else {
+                word[u] = col[u][0] >= 0 ? __float_as_uint(a[col[u][0]]) : 0u;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int w = w0 + 256 * u;
+            if (w < nw) {
+                kw[w] = word[u];
+#pragma unroll
+                for (int e = 0; e < EPD; ++e) {
+                    const uint32_t k = key_bits(word[u], e);
+                    if (k != 0 && k <= 0x7f800000u) atomicAdd(&hist[(k >> 19) & 0xfffu], 1u);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int nwd = (n_dead + EPD - 1) / EPD;                 // dwords that hold list entries
+    const int levels = DT == MTC_BF16 ? 2 : 3;
+    uint32_t prefix = 0, k_rem = k_aux, n_gt = 0;
+    bool all_pos = false;
+    for (int level = 0; level < levels && !all_pos; ++level) {
+        const int sh = level == 0 ? 19 : (level == 1 ? 7 : 0);
+        const uint32_t fm = level == 2 ? 0x7fu : 0xfffu;
+        const uint32_t pm = level == 0 ? 0u : (level == 1 ? 0xfff80000u : 0xffffff80u);
+        if (level > 0) {
+            for (int i = t; i < 4096; i += 256) hist[i] = 0;
+            if (t == 0) s_bin = 0xffffffffu;
+            __syncthreads();
+            for (int w = t; w < nwd; w += 256) {
+                const uint32_t word = kw[w];
+#pragma unroll
+                for (int e = 0; e < EPD; ++e) {
+                    const uint32_t k = key_bits(word, e);
+                    if (k != 0 && k <= 0x7f800000u && ((k ^ prefix) & pm) == 0) atomicAdd(&hist[(k >> sh) & fm], 1u);
+                }
+            }
+            __syncthreads();
+        }
+        // thread t owns bins [16t, 16t+15]; suffix sums over the threads: in the wave by shuffles, across waves through LDS
+        uint32_t h[16], mine = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { h[i] = hist[16 * t + i]; mine += h[i]; }
+        uint32_t suf = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_down(suf, off);
+            if (lane + off < 64) suf += o;
+        }
+        if (lane == 0) wtot[wave] = suf;
+        __syncthreads();
+        uint32_t above = suf - mine, total = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < 4; ++w2) { total += wtot[w2]; if (w2 > wave) above += wtot[w2]; }
+#pragma unroll
+        for (int i = 15; i >= 0; --i) {
+            if (above < k_rem && k_rem <= above + h[i]) { s_bin = 16 * t + i; s_above = above; s_h = h[i]; }
+            above += h[i];
+        }
+        __syncthreads();
+        if (s_bin == 0xffffffffu) {            // fewer positives than k_aux: take them all
+            all_pos = true; n_gt = total;
+        } else {
+            n_gt += s_above; k_rem -= s_above; prefix |= s_bin << sh;
+        }
+        __syncthreads();
+    }
+    const uint32_t tau = all_pos ? 0u : prefix, quota = all_pos ? 0u : k_rem;
+    if (t == 0) {
+        row_cnt[row] = all_pos ? n_gt : k_aux;
+        row_tau[row] = tau;
+        row_quota[row] = quota;
+    }
+    // ---- ties at tau beyond the quota: the first `quota` of them in list order are taken.  Only then is the order needed:
+    // every thread counts the ties of one contiguous piece of the list (odd dword pitch: conflict-free), an exclusive
+    // scan over the threads finds the piece holding the quota-th tie, whose owner finds its position
+    if (!all_pos && quota < s_h) {
+        const int lw = ((nwd + 255) / 256) | 1;
+        const int wb = t * lw, we = min(wb + lw, nwd);
+        uint32_t c = 0;
+        for (int w = wb; w < we; ++w) {
+            const uint32_t word = kw[w];
+#pragma unroll
+            for (int e = 0; e < EPD; ++e) c += key_bits(word, e) == tau ? 1u : 0u;
+        }
+        uint32_t inc = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(inc, off);
+            if (lane >= off) inc += o;
+        }
+        if (lane == 63) wtot[wave] = inc;
+        __syncthreads();
+        uint32_t excl = inc - c;
+#pragma unroll
+        for (int w2 = 0; w2 < 4; ++w2) if (w2 < wave) excl += wtot[w2];
+        if (excl < quota && quota <= excl + c) {
+            uint32_t need = quota - excl;
+            for (int w = wb; w < we && need; ++w) {
+                const uint32_t word = kw[w];
+#pragma unroll
+                for (int e = 0; e < EPD; ++e)
+                    if (need && key_bits(word, e) == tau && --need == 0) s_cut = (uint32_t)(w * EPD + e);
+            }
+        }
+        __syncthreads();
+    }
+    const uint32_t cut = s_cut;               // index of the last tie taken (0xffffffff: all of them)
+    for (int w = 2 * t; w < nw; w += 512) {
+        const uint2 in = *reinterpret_cast<const uint2*>(&kw[w]);
+        uint32_t wd[2] = {in.x, in.y};
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            uint32_t keep = 0;
+#pragma unroll
+            for (int e = 0; e < EPD; ++e) {
+                const uint32_t k = key_bits(wd[q], e);
+                const uint32_t i = (uint32_t)((w + q) * EPD + e);
+                const bool ok = k != 0 && k <= 0x7f800000u;
+                const bool sel = ok && (k > tau || (quota && k == tau && i <= cut));
+                if (sel) keep |= EPD == 2 ? (0xffffu << (16 * e)) : 0xffffffffu;
+            }
+            wd[q] &= keep;
+        }
+        o2[w >> 1] = make_uint2(wd[0], wd[1]);
     }
 }
 
@@ -376,27 +594,60 @@ __global__ __launch_bounds__(256) void aux_mask_kernel(size_t n, const void* __r
 }
 
 // dst[c][r] = src[row(r)][c] for r < R, c < C (row(r) = src_rows[r] when given: gather + transpose in one pass);
-// columns R <= r < R_pad of dst are zero-filled (GEMM operands padded to the k-tile).  64 x 64 tiles through LDS.
+// columns R <= r < R_pad of dst are zero-filled (GEMM operands padded to the k-tile).  128 x 128 (bf16) / 64 x 64 (fp32)
+// tiles through LDS: both the reads (rows of src) and the writes (rows of dst) move 256-byte row pieces, 4 elements per lane.
 template <typename T>
 __global__ __launch_bounds__(256) void transpose_rows_kernel(int R, int C, int R_pad, const T* __restrict__ src, long long ld_src,
                                                              const int32_t* __restrict__ src_rows, T* __restrict__ dst,
                                                              long long ld_dst) {
-    __shared__ T tile[64][65];
-    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    for (int i = ty; i < 64; i += 4) {
-        const int r = r0 + i, c = c0 + tx;
-        T v = (T)0;
-        if (r < R && c < C) {
-            const long long rr = src_rows ? (long long)src_rows[r] : (long long)r;
-            v = src[(size_t)rr * ld_src + c];
+    struct alignas(4 * sizeof(T)) Vec4 { T e[4]; };
+    constexpr int TS = sizeof(T) == 2 ? 128 : 64;               // 33 KB / 17 KB of LDS
+    __shared__ T tile[TS][TS + (sizeof(T) == 2 ? 2 : 1)];      // row pitch = 65 / 65 dwords (odd): column reads spread over the banks
+    const int r0 = blockIdx.x * TS, c0 = blockIdx.y * TS;
+    const int t = threadIdx.x;
+    // load: thread covers 4 consecutive columns of one row per pass; TS / 4 threads span a row piece
+    constexpr int TPR = TS / 4, RPP = 256 / TPR;               // threads per row piece, rows per pass
+    {
+        const int cq = (t % TPR) * 4, rr = t / TPR;
+        for (int i = rr; i < TS; i += RPP) {
+            const int r = r0 + i;
+            T v[4] = {(T)0, (T)0, (T)0, (T)0};
+            if (r < R) {
+                const long long row = src_rows ? (long long)src_rows[r] : (long long)r;
+                const T* p = src + (size_t)row * ld_src + c0 + cq;
+                if (c0 + cq + 3 < C && ((uintptr_t)p & (4 * sizeof(T) - 1)) == 0) {      // one 8- / 16-byte request
+                    const Vec4 w = *reinterpret_cast<const Vec4*>(p);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = w.e[q];
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (c0 + cq + q < C) v[q] = p[q];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tile[i][cq + q] = v[q];
         }
-        tile[i][tx] = v;
     }
     __syncthreads();
-    for (int i = ty; i < 64; i += 4) {
-        const int c = c0 + i, r = r0 + tx;
-        if (c < C && r < R_pad) dst[(size_t)c * ld_dst + r] = tile[tx][i];
+    // store: thread covers 4 consecutive r of one dst row (= source column) per pass
+    {
+        const int rq = (t % TPR) * 4, cc = t / TPR;
+        for (int i = cc; i < TS; i += RPP) {
+            const int c = c0 + i;
+            if (c >= C) continue;
+            T* p = dst + (size_t)c * ld_dst + r0 + rq;
+            if (r0 + rq + 3 < R_pad && ((uintptr_t)p & (4 * sizeof(T) - 1)) == 0) {
+                Vec4 w;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) w.e[q] = tile[rq + q][i];
+                *reinterpret_cast<Vec4*>(p) = w;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (r0 + rq + q < R_pad) p[q] = tile[rq + q][i];
+            }
+        }
     }
 }
 
@@ -405,7 +656,8 @@ __global__ __launch_bounds__(256) void transpose_rows_kernel(int R, int C, int R
 // once to the model dtype.  One wave per dead feature.
 template <int DT>
 __global__ __launch_bounds__(256) void aux_mask_rowsum_kernel(int n, int B, const void* __restrict__ a_, long long ld_a,
-                                                              void* __restrict__ d_, long long ld_d, void* __restrict__ e_b) {
+                                                              void* __restrict__ d_, long long ld_d, void* __restrict__ e_b,
+                                                              int vec8) {
     typedef DType<DT> D_;
     typedef typename D_::T T;
     const int lane = threadIdx.x & 63;
@@ -414,9 +666,20 @@ __global__ __launch_bounds__(256) void aux_mask_rowsum_kernel(int n, int B, cons
     const T* a = reinterpret_cast<const T*>(a_) + (size_t)j * ld_a;
     T* d = reinterpret_cast<T*>(d_) + (size_t)j * ld_d;
     float s = 0.f;
-    for (int b = lane; b < B; b += 64) {
-        if (D_::ld(a + b) > 0.f) s += D_::ld(d + b);
-        else d[b] = (T)0;
+    if (vec8) {                       // rows in 8-element pieces (host: B, both strides and both bases allow it)
+        for (int b = lane * 8; b < B; b += 512) {
+            float av[8], dv[8];
+            load8<DT>(a, (size_t)b, av);
+            load8<DT>(d, (size_t)b, dv);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { dv[i] = av[i] > 0.f ? dv[i] : 0.f; s += dv[i]; }
+            store8<DT>(d, (size_t)b, dv);
+        }
+    } else {
+        for (int b = lane; b < B; b += 64) {
+            if (D_::ld(a + b) > 0.f) s += D_::ld(d + b);
+            else d[b] = (T)0;
+        }
     }
     s = wave_sum(s);
     if (lane == 0) D_::st(reinterpret_cast<T*>(e_b) + j, s);
@@ -448,7 +711,8 @@ extern "C" int mtc_transpose_rows(int32_t dtype, int32_t R, int32_t C, int32_t R
     MTC_REQUIRE(R >= 0 && C >= 0 && R_pad >= R && ld_src >= C && ld_dst >= R_pad, "mtc_transpose_rows: bad sizes");
     if (C == 0 || R_pad == 0) return 0;
     MTC_REQUIRE(src && dst, "mtc_transpose_rows: null pointer");
-    const dim3 grid((R_pad + 63) / 64, (C + 63) / 64), block(256);
+    const int ts = dtype == MTC_BF16 ? 128 : 64;
+    const dim3 grid((R_pad + ts - 1) / ts, (C + ts - 1) / ts), block(256);
     if (dtype == MTC_BF16)
         hipLaunchKernelGGL(transpose_rows_kernel<u16>, grid, block, 0, as_stream(stream), R, C, R_pad, (const u16*)src,
                            (long long)ld_src, src_rows, (u16*)dst, (long long)ld_dst);
@@ -464,12 +728,13 @@ extern "C" int mtc_aux_mask_rowsum(int32_t dtype, int32_t n, int32_t B, const vo
     if (n <= 0) return 0;
     MTC_REQUIRE(acts_auxT && d_actsT && e_b && B > 0 && ld_a >= B && ld_d >= B, "mtc_aux_mask_rowsum: bad arguments");
     const dim3 grid((n + 3) / 4), block(256);
+    const int vec8 = B % 8 == 0 && ld_a % 8 == 0 && ld_d % 8 == 0 && (((uintptr_t)acts_auxT | (uintptr_t)d_actsT) & 15) == 0;
     if (dtype == MTC_BF16)
         hipLaunchKernelGGL(aux_mask_rowsum_kernel<MTC_BF16>, grid, block, 0, as_stream(stream), n, B, acts_auxT, (long long)ld_a,
-                           d_actsT, (long long)ld_d, e_b);
+                           d_actsT, (long long)ld_d, e_b, vec8);
     else
         hipLaunchKernelGGL(aux_mask_rowsum_kernel<MTC_F32>, grid, block, 0, as_stream(stream), n, B, acts_auxT, (long long)ld_a,
-                           d_actsT, (long long)ld_d, e_b);
+                           d_actsT, (long long)ld_d, e_b, vec8);
     return check_launch("mtc_aux_mask_rowsum");
 }
 
@@ -558,6 +823,31 @@ extern "C" int mtc_aux_dense_fill(const mtc_desc* d, const void* acts, const int
         hipLaunchKernelGGL(aux_dense_fill_kernel<MTC_F32>, grid, block, 0, as_stream(stream), acts, d->B, d->D, n_pad, dead_idx,
                            n_dead_dev, row_tau_bits, row_tie_quota, acts_aux);
     return check_launch("mtc_aux_dense_fill");
+}
+
+extern "C" int mtc_aux_select_dense(const mtc_desc* d, const void* acts, const int32_t* dead_idx, const int32_t* n_dead_dev,
+                                    int32_t top_k_aux, int32_t n_pad, uint32_t* row_cnt, uint32_t* row_tau_bits,
+                                    uint32_t* row_tie_quota, void* acts_aux, void* stream) {
+    if (check_desc(d, "mtc_aux_select_dense")) return -1;
+    MTC_REQUIRE(acts && dead_idx && n_dead_dev && row_cnt && row_tau_bits && row_tie_quota && acts_aux,
+                "mtc_aux_select_dense: null pointer");
+    MTC_REQUIRE(top_k_aux >= 0, "mtc_aux_select_dense: top_k_aux must be >= 0");
+    MTC_REQUIRE(n_pad > 0 && n_pad <= d->D, "mtc_aux_select_dense: n_pad must be in 1..D");
+    const size_t es = d->dtype == MTC_BF16 ? 2 : 4;
+    const size_t lds = (size_t)n_pad * es;
+    // one pass with the row's dead columns held in LDS when they fit beside the histogram (and rows of acts_aux take
+    // 8-byte stores); the two-launch form otherwise -- same result either way
+    if (lds <= 40 * 1024 && n_pad % (int)(8 / es) == 0 && ((uintptr_t)acts_aux & 7) == 0 && ((uintptr_t)dead_idx & 7) == 0) {
+        if (d->dtype == MTC_BF16)
+            hipLaunchKernelGGL(aux_select_dense_kernel<MTC_BF16>, dim3(d->B), dim3(256), lds, as_stream(stream), acts, d->D, n_pad,
+                               dead_idx, n_dead_dev, top_k_aux, row_cnt, row_tau_bits, row_tie_quota, acts_aux);
+        else
+            hipLaunchKernelGGL(aux_select_dense_kernel<MTC_F32>, dim3(d->B), dim3(256), lds, as_stream(stream), acts, d->D, n_pad,
+                               dead_idx, n_dead_dev, top_k_aux, row_cnt, row_tau_bits, row_tie_quota, acts_aux);
+        return check_launch("mtc_aux_select_dense");
+    }
+    if (mtc_aux_select(d, acts, dead_idx, n_dead_dev, top_k_aux, row_cnt, row_tau_bits, row_tie_quota, stream)) return -1;
+    return mtc_aux_dense_fill(d, acts, dead_idx, n_dead_dev, row_tau_bits, row_tie_quota, n_pad, acts_aux, stream);
 }
 
 extern "C" int mtc_aux_row_candidates(const mtc_desc* d, const void* acts, const int32_t* dead_idx, const int32_t* n_dead_dev,

@@ -159,6 +159,10 @@ __global__ __launch_bounds__(256, (DT == MTC_BF16 ? (NC <= 5 ? MTC_FUSED_WAVES :
         load_row<DT, NC>(make_rsrc(W), (uint32_t)A * (uint32_t)sizeof(T), j, co, pw);
     }
     const int s0 = col_ptr[j], e_end = col_ptr[j + 1];
+    // (requested with the column pointers: asked for after the gather loop it cost every wave one more round trip
+    // before its moment rows could be requested, +80 us on the launch)
+    int xr = -1;
+    if constexpr (EXTRA != 0) xr = __builtin_amdgcn_readfirstlane(extra_row[j]);
     for (int e0 = s0; e0 < e_end; e0 += 64) {
         const int nb = min(64, e_end - e0);
         int my_row = 0, my_pos = 0; float my_c = 0.f;
@@ -177,28 +181,35 @@ __global__ __launch_bounds__(256, (DT == MTC_BF16 ? (NC <= 5 ? MTC_FUSED_WAVES :
     // the .grad a dense backward would hold: rounded to the parameter dtype and kept in storage
     // form (bf16: 4 registers per chunk instead of 8), which frees the registers for the parameter
     // and moment rows -- all of them are requested before any is consumed
-#pragma unroll
-    for (int c = 0; c < NC; ++c)
-        if (rc.valid(c)) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) acc[c][q] *= scale;
-            gr[c] = pack_raw<DT>(acc[c]);
-        }
-    int xr = -1;
     if constexpr (EXTRA != 0) {
-        xr = __builtin_amdgcn_readfirstlane(extra_row[j]);
+        // on the accumulators, before they are packed (packing first and unpacking per chunk made the compiler spill 68
+        // registers, and a launch with a scratch segment starts its waves more slowly: +80 us)
         if (xr >= 0) {
 #pragma unroll
             for (int c = 0; c < NC; ++c)
                 if (rc.valid(c)) {
-                    float a[8], b[8];
-                    unpack(gr[c], a);
+                    float b[8];
                     load8<DT>(extra, (size_t)xr * A + rc.off(c), b);
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) a[q] = D_::rnd(a[q] + b[q]);
-                    gr[c] = pack_raw<DT>(a);
+                    for (int q = 0; q < 8; ++q) acc[c][q] = D_::rnd(D_::rnd(acc[c][q] * scale) + b[q]);
                 }
+        } else {
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc[c][q] *= scale;
         }
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            if (rc.valid(c)) gr[c] = pack_raw<DT>(acc[c]);
+    } else {
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            if (rc.valid(c)) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc[c][q] *= scale;
+                gr[c] = pack_raw<DT>(acc[c]);
+            }
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -310,6 +321,8 @@ __global__ __launch_bounds__(256, 8) void fused_enc_sliced_kernel(
     const size_t off = (size_t)(jv ? j : 0) * A + col0;
     const int s0 = jv ? col_ptr[j] : 0;
     const int n = jv ? col_ptr[j + 1] - s0 : 0;
+    int xr = -1;
+    if constexpr (EXTRA != 0) xr = jv ? extra_row[j] : -1;    // with the column pointers: long back when it is needed
     int nmax = n;
 #pragma unroll
     for (int o = LPF; o < 64; o <<= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
@@ -372,9 +385,7 @@ __global__ __launch_bounds__(256, 8) void fused_enc_sliced_kernel(
     float g[8], w[8], mm[8], vv[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) g[e] = D_::rnd(acc[e] * scale);          // the .grad a dense backward would hold
-    int xr = -1;
     if constexpr (EXTRA != 0) {
-        xr = extra_row[j];
         if (xr >= 0) {
             float b[8];
             load8<DT>(extra, (size_t)xr * A + col0, b);

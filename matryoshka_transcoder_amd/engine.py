@@ -372,12 +372,10 @@ class HotPath:
         row_cnt = torch.empty(B, dtype=torch.int32, device=dev)
         row_tau = torch.empty(B, dtype=torch.int32, device=dev)
         row_quota = torch.empty(B, dtype=torch.int32, device=dev)
-        check(lib.mtc_aux_select(C.byref(d), _p(acts), _p(dead_idx), _p(n_dead), int(top_k_aux), _p(row_cnt), _p(row_tau),
-                                 _p(row_quota), s), "mtc_aux_select")
         n_pad = self._aux_bucket(dead.cap, self.D)
         acts_aux = torch.empty(B, n_pad, dtype=self.dtype, device=dev)
-        check(lib.mtc_aux_dense_fill(C.byref(d), _p(acts), _p(dead_idx), _p(n_dead), _p(row_tau), _p(row_quota), n_pad,
-                                     _p(acts_aux), s), "mtc_aux_dense_fill")
+        check(lib.mtc_aux_select_dense(C.byref(d), _p(acts), _p(dead_idx), _p(n_dead), int(top_k_aux), n_pad, _p(row_cnt),
+                                       _p(row_tau), _p(row_quota), _p(acts_aux), s), "mtc_aux_select_dense")
         return self._aux_dense_tail(d, dead, acts_aux, n_pad, aux_penalty, W_dec, x_target, x_hat, std, g, need_grad,
                                     reduce_partial, n_dead if global_active is None else global_active)
 

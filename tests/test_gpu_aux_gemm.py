@@ -80,16 +80,16 @@ def test_transpose_rows_mask_rowsum_scatter_add(dt, gpu_lib):
     assert torch.equal(dst.cpu(), want)
     assert torch.equal(hp.transpose_rows(src.to(DEV), 150, 200).cpu(), src.t().contiguous())
     # mask + row sums on the transposed layout
-    n, B = 37, 300
-    a = torch.randn(n, B, generator=g).clamp_min(0).to(dt)
-    d = torch.randn(n, B, generator=g).to(dt)
-    a_d, dd, e_b = a.to(DEV), d.clone().to(DEV), torch.empty(n, dtype=dt, device=DEV)     # operands stay referenced
-    _lib_check(hp.lib.mtc_aux_mask_rowsum(hp.code, n, B, _ptr(a_d), B, _ptr(dd), B, _ptr(e_b), None))
-    torch.cuda.synchronize()
-    masked = torch.where(a > 0, d, torch.zeros((), dtype=dt))
-    assert torch.equal(dd.cpu(), masked)
-    rt, at = (1e-5, 1e-5) if dt == torch.float32 else (1e-2, 1e-2)
-    _close(e_b.float(), masked.float().sum(1), rt, at, "row sums")
+    for n, B in ((37, 300), (37, 1544)):              # element-wise rows; 8-element pieces (B % 8 == 0)
+        a = torch.randn(n, B, generator=g).clamp_min(0).to(dt)
+        d = torch.randn(n, B, generator=g).to(dt)
+        a_d, dd, e_b = a.to(DEV), d.clone().to(DEV), torch.empty(n, dtype=dt, device=DEV)     # operands stay referenced
+        _lib_check(hp.lib.mtc_aux_mask_rowsum(hp.code, n, B, _ptr(a_d), B, _ptr(dd), B, _ptr(e_b), None))
+        torch.cuda.synchronize()
+        masked = torch.where(a > 0, d, torch.zeros((), dtype=dt))
+        assert torch.equal(dd.cpu(), masked)
+        rt, at = (1e-5, 1e-5) if dt == torch.float32 else (1e-2, 1e-2)
+        _close(e_b.float(), masked.float().sum(1), rt, at, "row sums")
     # grad[dead] += rows with the live count on the device: rows beyond it are left alone
     dst0 = torch.randn(64, 48, generator=g).to(dt)
     add = torch.randn(16, 48, generator=g).to(dt)
@@ -127,6 +127,56 @@ def test_dead_list_tail_bound_and_map(gpu_lib):
     rm = torch.full((1000,), -1, dtype=torch.int32)
     rm[dead] = torch.arange(n, dtype=torch.int32)
     assert torch.equal(dl.row_map.cpu(), rm)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("B,D,n_dead,n_pad,k_aux,coarse", [
+    (37, 3000, 700, 768, 64, False),        # the common case: threshold inside the positives
+    (37, 3000, 700, 768, 64, True),         # values on a coarse grid: many ties at every threshold, quota < ties
+    (9, 3000, 700, 1024, 600, False),       # fewer positives than k_aux: every positive one is taken
+    (5, 512, 1, 128, 8, False),             # one dead feature
+    (5, 512, 0, 128, 8, False),             # none: zero rows
+    (6, 30000, 24000, 24064, 512, True),    # beyond the LDS budget: the entry falls back to the two launches
+    (6, 1000, 333, 334, 50, True),          # odd width: no 8-byte rows -> fallback (bf16), fused (fp32)
+])
+def test_select_dense_one_pass_equals_select_then_fill(dt, B, D, n_dead, n_pad, k_aux, coarse, gpu_lib):
+    """mtc_aux_select_dense against mtc_aux_select + mtc_aux_dense_fill (bit for bit: counts, threshold bits, tie quotas,
+    acts_aux), and against the definition (sae.py:332-336: top-k_aux of the dead columns, ties to the lower feature)."""
+    g = torch.Generator("cpu").manual_seed(B * 7 + n_dead)
+    hp = _hp(dt, D=D)
+    d = hp.desc(B)
+    acts = torch.randn(B, D, generator=g)
+    if coarse:
+        acts = (acts * 4).round() / 4
+    acts = acts.clamp_min(0).to(dt)
+    dead = torch.sort(torch.randperm(D, generator=g)[:n_dead]).values
+    dead_idx = torch.zeros(D, dtype=torch.int32)
+    dead_idx[:n_dead] = dead.to(torch.int32)
+    acts_d, idx_d = acts.to(DEV), dead_idx.to(DEV)
+    n_d = torch.tensor([n_dead], dtype=torch.int32, device=DEV)
+    i32 = dict(dtype=torch.int32, device=DEV)
+    c1, t1, q1 = (torch.full((B,), -7, **i32) for _ in range(3))
+    c2, t2, q2 = (torch.full((B,), -7, **i32) for _ in range(3))
+    a1 = torch.full((B, n_pad), float("nan"), dtype=dt, device=DEV)
+    a2 = torch.full((B, n_pad), float("nan"), dtype=dt, device=DEV)
+    lib = hp.lib
+    _lib_check(lib.mtc_aux_select(C.byref(d), _ptr(acts_d), _ptr(idx_d), _ptr(n_d), k_aux, _ptr(c1), _ptr(t1), _ptr(q1), None))
+    _lib_check(lib.mtc_aux_dense_fill(C.byref(d), _ptr(acts_d), _ptr(idx_d), _ptr(n_d), _ptr(t1), _ptr(q1), n_pad, _ptr(a1), None))
+    _lib_check(lib.mtc_aux_select_dense(C.byref(d), _ptr(acts_d), _ptr(idx_d), _ptr(n_d), k_aux, n_pad, _ptr(c2), _ptr(t2),
+                                        _ptr(q2), _ptr(a2), None))
+    torch.cuda.synchronize()
+    assert torch.equal(c1, c2) and torch.equal(t1, t2) and torch.equal(q1, q2)
+    assert torch.equal(a1.view(torch.int16 if dt == torch.bfloat16 else torch.int32),
+                       a2.view(torch.int16 if dt == torch.bfloat16 else torch.int32))
+    # the definition: stable sort of the dead columns by value (descending), the first k positives stay
+    sub = acts[:, dead.long()].float()
+    want = torch.zeros(B, n_pad)
+    if n_dead:
+        order = torch.sort(sub, dim=1, descending=True, stable=True).indices[:, :min(k_aux, n_dead)]
+        keep = torch.zeros_like(sub, dtype=torch.bool).scatter_(1, order, True) & (sub > 0)
+        want[:, :n_dead] = torch.where(keep, sub, torch.zeros(()))
+    assert torch.equal(a2.float().cpu(), want)
+    assert torch.equal(c2.cpu().long(), (want > 0).sum(1))
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
