@@ -123,6 +123,10 @@ __global__ __launch_bounds__(256) void unitnorm_rows_kernel(int D, int A, void* 
 #ifndef MTC_FUSED_WAVES
 #define MTC_FUSED_WAVES 3
 #endif
+#ifndef MTC_FUSED_WAVES_WIDE
+#define MTC_FUSED_WAVES_WIDE 1          // rows of 8+ chunks per lane (A = 4608, the 27B shapes): at 2 waves per SIMD the
+                                        // decoder form spills 67 registers inside its gather loop (7.70 vs 6.53 ms per step)
+#endif
 //   WITH_DOT = 1 (decoder rows only): the same gather of g also produces d a_bj = g_b . W_dec[j] + l1_term
 //   for the feature's entries (d_vals_out[csc_pos]), which replaces the decode kernel's second sweep.
 //   EXTRA = 1: a second, dense gradient contribution for some rows (the auxiliary branch's GEMM results over the dead
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(256) void unitnorm_rows_kernel(int D, int A, void* 
 //   rounded sparse gradient of feature j, with the rounding a dense `grad += ...` would make.  EXTRA = 0 compiles to
 //   the kernel without these operands.
 template <int DT, int COEF_DT, int NC, int PROJECT, int WITH_DOT, int EXTRA>
-__global__ __launch_bounds__(256, (DT == MTC_BF16 ? (NC <= 5 ? MTC_FUSED_WAVES : 2) : (NC <= 2 ? 4 : NC <= 5 ? 2 : 1))) void fused_grad_adam_kernel(
+__global__ __launch_bounds__(256, (DT == MTC_BF16 ? (NC <= 5 ? MTC_FUSED_WAVES : NC <= 7 ? 2 : MTC_FUSED_WAVES_WIDE) : (NC <= 2 ? 4 : NC <= 5 ? 2 : 1))) void fused_grad_adam_kernel(
     int D, int A, const int32_t* __restrict__ col_ptr, const int32_t* __restrict__ csc_row,
     const int32_t* __restrict__ csc_pos, const void* __restrict__ coef, const void* __restrict__ src,
     const float* __restrict__ scale_p, void* __restrict__ W, void* __restrict__ m, void* __restrict__ v,
