@@ -210,7 +210,9 @@ int mtc_decode_finish(const mtc_desc* d, int32_t B_total, const float* partial_l
 /* a8/a10/a14  scalar epilogue: reduces row_stats (and the optional aux partials) to the
  * reference's output scalars without leaving the device.
  *   scalars (float[16]): 0 l2  1 l1  2 l0  3 l1_norm  4 aux  5 loss  6 fvu  7 fvu_min  8 fvu_max
- *                        9 fvu_mean  10 var(x_t)  11 nnz  12..15 reserved
+ *                        9 fvu_mean  10 var(x_t)  11 nnz  12..15: fp32 descriptors 0; bf16 descriptors 8 bf16 values
+ *                        {l2, l1, l1_norm, 0 (aux while no feature is dead), loss of the aux-free form with every op
+ *                        rounded (sae.py:245), 0, 0, 0}: the model-dtype scalars of the output dict without a conversion
  * l2/l1/l1_norm are rounded to the model dtype (sae.py:236-239), the rest are fp32.
  * n_rows_total/n_feat_total: global B and D (they differ from d->D when sharded). */
 int mtc_reduce_scalars(const mtc_desc* d, const float* row_stats, const float* aux_rows /*[B] or NULL*/,

@@ -341,7 +341,19 @@ __global__ __launch_bounds__(1024) void reduce_scalars_kernel(int B, int A_t, in
     scalars[0] = l2; scalars[1] = l1; scalars[2] = l0; scalars[3] = l1n; scalars[4] = aux; scalars[5] = loss;
     scalars[6] = flast; scalars[7] = fmin; scalars[8] = fmax; scalars[9] = fsum / (float)G;
     scalars[10] = var_t; scalars[11] = (float)nnz;
-    scalars[12] = scalars[13] = scalars[14] = scalars[15] = 0.f;
+    // 12..15: for bf16 models, the model-dtype values a caller hands out (l2, l1, l1_norm, aux = 0, and the loss as the
+    // reference forms it while no feature is dead: every op rounded, sae.py:245,331) packed as 8 bf16 -- the host
+    // wrapper views them instead of launching a conversion of this vector every step
+    if constexpr (DT == MTC_BF16) {
+        const float loss_dt = D_::rnd(D_::rnd(l2 + D_::rnd(l1_coeff * l1)) + 0.f);
+        uint32_t* pk = reinterpret_cast<uint32_t*>(scalars + 12);
+        pk[0] = f32_to_bf16_bits(l2) | (f32_to_bf16_bits(l1) << 16);
+        pk[1] = f32_to_bf16_bits(l1n);                     // (aux: +0 in the high half)
+        pk[2] = f32_to_bf16_bits(loss_dt);
+        pk[3] = 0u;
+    } else {
+        scalars[12] = scalars[13] = scalars[14] = scalars[15] = 0.f;
+    }
 }
 
 static DecodeParams make_params(const mtc_desc* d, float l1_term) {

@@ -43,7 +43,12 @@ class _StepFn(torch.autograd.Function):
         module._last_res = res
         ctx.mark_non_differentiable(res.x_hat, res.scalars)
         loss32 = res.scalars[5]
-        loss = loss32.clone() if module._aux_is_on(res) else loss32.to(module.dtype)
+        if module._aux_is_on(res):
+            loss = loss32.clone()
+        elif module.dtype == torch.bfloat16:
+            loss = res.scalars[12:16].view(torch.bfloat16)[4].clone()     # the aux-free loss in the model dtype (mtc_reduce_scalars)
+        else:
+            loss = loss32.to(module.dtype)
         return loss, res.x_hat, res.scalars
 
     @staticmethod
@@ -425,25 +430,29 @@ class MatryoshkaTranscoder(nn.Module):
         self._flush_deferred()
         s, dt = res.scalars, self.dtype
         aux_on = self._aux_is_on(res)
-        # the kernel already rounded l2 / l1 / l1_norm / loss to the model dtype (mtc_reduce_scalars), so ONE conversion of
-        # the 16-float vector yields all of them exactly (a no-op for fp32 models); the entries are views of it
-        sd = s.to(dt)
+        # the kernel already rounded l2 / l1 / l1_norm / loss to the model dtype and, for bf16 models, left them as bf16
+        # in slots 12..15 of the vector (mtc_reduce_scalars): the entries below are views, no conversion launch per step
+        if dt == torch.bfloat16:
+            pk = s[12:16].view(torch.bfloat16)              # {l2, l1, l1_norm, 0, aux-free loss, 0, 0, 0}
+            l2, l1, l1n, zero, loss_dt = pk[0], pk[1], pk[2], pk[3], pk[4]
+        else:
+            l2, l1, l1n, zero, loss_dt = s[0], s[1], s[3], s[4], s[5]
         if loss is None:
-            loss = s[5].clone() if aux_on else sd[5]
+            loss = s[5].clone() if aux_on else loss_dt
         # aux inactive: a 0-dim zero in the target dtype (slot 4 holds 0 then); active: fp32 (sae.py:342-347)
         if aux_on:
             aux_loss = s[4]
         elif x_target.dtype == dt:
-            aux_loss = sd[4]
+            aux_loss = zero
         else:
             aux_loss = torch.zeros((), dtype=x_target.dtype, device=x_target.device)
         return {
             "transcoder_out": res.x_hat,
             "loss": loss,
-            "l2_loss": sd[0],
-            "l1_loss": sd[1],
+            "l2_loss": l2,
+            "l1_loss": l1,
             "l0_norm": s[2],
-            "l1_norm": sd[3],
+            "l1_norm": l1n,
             "aux_loss": aux_loss,
             "fvu": s[6],
             "fvu_min": s[7],
