@@ -128,6 +128,18 @@ class _Comm:
             work.wait()                                        # stream-level wait: the host does not block
         return out
 
+    def all_gather_begin(self, t: torch.Tensor):
+        """all_gather that runs beside whatever the caller enqueues next (see reduce_scatter_begin); all_gather_end()
+        makes the current stream wait for it and returns [world, ...]."""
+        if self.staged:
+            return (None, self.all_gather(t), None)
+        t = t.contiguous()
+        out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        work = dist.all_gather_into_tensor(out, t, group=self.group, async_op=True)
+        return (work, out.reshape((self.world,) + tuple(t.shape)), t)
+
+    all_gather_end = reduce_scatter_end
+
     def all_gather(self, t: torch.Tensor) -> torch.Tensor:
         if self.staged and t.is_cuda:
             h = t.cpu()
@@ -198,6 +210,11 @@ class _LibComm:
     @staticmethod
     def reduce_scatter_end(handle) -> torch.Tensor:
         return handle[1]
+
+    def all_gather_begin(self, t: torch.Tensor):
+        return (None, self.all_gather(t), None)              # in stream order (no second stream here)
+
+    all_gather_end = reduce_scatter_end
 
     def all_gather(self, t: torch.Tensor) -> torch.Tensor:
         t = t.contiguous()
@@ -451,24 +468,35 @@ class ShardedMatryoshkaTranscoder(MatryoshkaTranscoder):
         std_l = std[lo:hi] if std is not None else None
         # one byte buffer per rank = {x_hat, g of its rows | per-row statistics | nnz, sum|a| of its shard}: ONE all-gather
         # hands every rank all of g (its features fire on any row), the full reconstruction and the loss inputs
+        # Inside the fused step with the aux branch off, nothing reads the reconstruction before the output dict is built:
+        # it is then gathered by a collective of its own that runs beside the backward kernels (half of the bytes leave
+        # the critical path, and x_hat arrives contiguous).
+        deferred = bool(getattr(self, "_defer_dvals", False))
+        split = deferred and not aux_active
         es = x_target.element_size()
-        n_xg, n_st = 2 * rps * A_t * es, (G + 4) * rps * 4
+        n_xg, n_st = (1 if split else 2) * rps * A_t * es, (G + 4) * rps * 4
         pack = torch.empty(n_xg + n_st + 8, dtype=torch.uint8, device=dev)
-        both_l = pack[:n_xg].view(self.dtype).view(2, rps, A_t)
+        both_l = pack[:n_xg].view(self.dtype).view(-1, rps, A_t)
+        x_hat_l = torch.empty(rps, A_t, dtype=self.dtype, device=dev) if split else both_l[0]
+        g_l = both_l[-1]
         stats_l = pack[n_xg:n_xg + n_st].view(torch.float32).view(G + 4, rps)
         nnz_abs_l = pack[n_xg + n_st:].view(torch.float32)
         stats_l.zero_()
         check(lib.mtc_shard_nnz_abs(C.byref(d), _p(abs_rows), _p(sel.state), _p(nnz_abs_l), s), "mtc_shard_nnz_abs")
         check(lib.mtc_decode_finish(C.byref(dl), B, _p(my_last), None, _p(b_dec), _p(x_target[lo:hi]), _p(mean_l), _p(std_l),
-                                    _p(both_l[0]), _p(both_l[1]), _p(stats_l), None, s), "mtc_decode_finish")
+                                    _p(x_hat_l), _p(g_l), _p(stats_l), None, s), "mtc_decode_finish")
         allp = self.comm.all_gather(pack)                                   # [W, bytes]
-        both = allp[:, :n_xg].view(self.dtype).view(W, 2, rps, A_t)
-        x_hat = both[:, 0].reshape(B, A_t)
-        g = both[:, 1].reshape(B, A_t).contiguous()
+        both = allp[:, :n_xg].view(self.dtype).view(W, -1, rps, A_t)
+        g = both[:, -1].reshape(B, A_t).contiguous()
         row_stats = allp[:, n_xg:n_xg + n_st].view(torch.float32).view(W, G + 4, rps).permute(1, 0, 2).reshape(G + 4, B).contiguous()
         nnz_abs = allp[:, n_xg + n_st:].view(torch.float32).sum(0).contiguous()
         l1_term = float(cfg["l1_coeff"]) / (B * self.total_dict_size)
-        x_hat = x_hat.contiguous()
+        xh_handle = None
+        if split:
+            xh_handle = self.comm.all_gather_begin(x_hat_l)                 # valid once finish_metrics() has joined it
+            x_hat = xh_handle[1].reshape(B, A_t)
+        else:
+            x_hat = both[:, 0].reshape(B, A_t).contiguous()
         pre_handle = self.comm.reduce_scatter_begin(p_pre) if G > 1 else None
         aux, aux_rows = None, None
         if aux_active:
@@ -477,11 +505,12 @@ class ShardedMatryoshkaTranscoder(MatryoshkaTranscoder):
         defer = getattr(self, "_defer_dvals", False) and (aux is None or bool(aux.get("dense")))
         d_vals = hp.decode_bwd_vals(d, sel, W_dec, g, l1_term) if need_grad and not defer else None
         scalars = torch.empty(16, dtype=torch.float32, device=dev)
-        deferred = bool(getattr(self, "_defer_dvals", False))
         # the deferred part runs after the optimizer kernels: it must see THIS step's b_dec (a few KB), not the updated one
         b_dec_fwd = b_dec.clone() if deferred and pre_handle is not None else b_dec
 
         def finish_metrics():
+            if xh_handle is not None:
+                self.comm.all_gather_end(xh_handle)                         # x_hat (the output dict's transcoder_out)
             # SSE of prefixes 0 .. G-2 on this rank's rows, gathered into the per-row statistics; then the scalars
             if pre_handle is not None:
                 my_pre = self.comm.reduce_scatter_end(pre_handle)[0]        # [G-1, rps, A_t]

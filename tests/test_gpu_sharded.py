@@ -48,6 +48,10 @@ def _train(model, opt, batches, fused=False):
             opt.step(project=True)
             opt.zero_grad()
         log.append({k: float(v.detach().float()) for k, v in out.items() if v.dim() == 0})
+        # the reconstruction too (the sharded fused step gathers it by a collective of its own, beside the backward kernels)
+        xh = out["transcoder_out"].detach().float()
+        log[-1]["transcoder_out |mean|"] = float(xh.abs().mean())
+        log[-1]["transcoder_out rms"] = float(xh.pow(2).mean().sqrt())
     return log
 
 
