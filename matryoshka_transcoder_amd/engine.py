@@ -400,7 +400,7 @@ class HotPath:
             ctx.update(acts_aux=acts_aux, g_aux=g_aux, W_dec=W_dec)
         return ctx, aux_rows
 
-    def aux_extra_rows(self, ctx, x_norm, g_loss=None):
+    def aux_extra_rows(self, ctx, x_norm, g_loss=None, side=None):
         """Gradient rows of the aux branch over the dead set (model dtype, one rounding per product like the reference's
         matmul backward), every product on mtc_gemm_nt in the feature-major layout the fused gradient kernels read:
         (E_dec [n_pad, A_t], E_enc [n_pad, A_s], e_b [n_pad]); rows of the padding are never referenced."""
@@ -415,12 +415,32 @@ class HotPath:
         e_b = torch.empty(n_pad, dtype=self.dtype, device=dev)
         check(self.lib.mtc_aux_mask_rowsum(self.code, n_pad, B, _p(acts_auxT), B, _p(d_actsT), B, _p(e_b), _stream()),
               "mtc_aux_mask_rowsum")
+        def enc_rows():
+            x_normT = self.transpose_rows(x_norm, B, self.A_s)                                     # [A_s][B]
+            E = torch.empty(n_pad, self.A_s, dtype=self.dtype, device=dev)
+            self.gemm_nt(n_pad, self.A_s, B, d_actsT, B, x_normT, B, E, self.A_s)
+            return E, x_normT
+
         g_auxT = self.transpose_rows(g_aux, B, self.A_t)                                           # [A_t][B]
-        x_normT = self.transpose_rows(x_norm, B, self.A_s)                                         # [A_s][B]
         E_dec = torch.empty(n_pad, self.A_t, dtype=self.dtype, device=dev)
-        E_enc = torch.empty(n_pad, self.A_s, dtype=self.dtype, device=dev)
         self.gemm_nt(n_pad, self.A_t, B, acts_auxT, B, g_auxT, B, E_dec, self.A_t)
-        self.gemm_nt(n_pad, self.A_s, B, d_actsT, B, x_normT, B, E_enc, self.A_s)
+        ctx["enc_rows_event"] = None
+        if side is None:
+            E_enc, _ = enc_rows()
+        else:
+            # the encoder rows are not needed before the SECOND gradient launch: their transpose + product run on the side
+            # stream beside the decoder-row launch (an MFMA-bound product under a fabric-bound gather kernel; started
+            # behind the E_dec product, which it would only slow down).  Operands the side stream reads / writes stay
+            # referenced in ctx until the next step (allocator safety across streams).
+            main = torch.cuda.current_stream()
+            e_dec = torch.cuda.Event()
+            e_dec.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(e_dec)
+                E_enc, x_normT = enc_rows()
+                ctx["enc_rows_event"] = torch.cuda.Event()
+                ctx["enc_rows_event"].record(side)
+            ctx["enc_rows_keep"] = (d_actsT, x_normT, E_enc)
         return E_dec, E_enc, e_b
 
     def aux_backward_dense(self, ctx, x_norm, g_loss, grads):
@@ -456,10 +476,12 @@ class HotPath:
               "mtc_adam_flat")
 
     def fused_backward_adam(self, d, sel: Selection, g, d_vals, x_norm, scale, W_dec, st_dec, W_encT, st_enc, b_enc,
-                            st_benc, h_dec: AdamHyper, h_enc: AdamHyper, h_benc: AdamHyper, l1_term: float = 0.0, extra=None):
+                            st_benc, h_dec: AdamHyper, h_enc: AdamHyper, h_benc: AdamHyper, l1_term: float = 0.0, extra=None,
+                            enc_wait=None):
         """a11 + a12 + a13 in two launches; st_* = (exp_avg, exp_avg_sq) in the storage layout of the parameter.
         d_vals=None: the decoder launch also produces d a_bj (the forward skipped its second sweep).
-        extra = (row_map int32[D], E_dec, E_enc, e_b): dense extra gradient rows (aux branch) added per feature."""
+        extra = (row_map int32[D], E_dec, E_enc, e_b): dense extra gradient rows (aux branch) added per feature;
+        enc_wait: event the current stream waits for between the two launches (E_enc made on another stream)."""
         dv_out = None
         if d_vals is None:
             d_vals = dv_out = torch.empty(max(sel.col_idx.numel(), 1), dtype=torch.float32, device=g.device)
@@ -488,6 +510,8 @@ class HotPath:
             C.byref(d), _p(sel.col_ptr), _p(sel.csc_row), _p(sel.csc_pos), _p(sel.vals), _p(g), _p(scale), _p(W_dec),
             _p(st_dec[0]), _p(st_dec[1]), C.byref(h_dec), _p(dv_out), float(l1_term), _p(row_map), _p(E_dec), csc_order, s),
             "mtc_fused_backward_adam_dec_extra")
+        if enc_wait is not None:
+            torch.cuda.current_stream().wait_event(enc_wait)
         check(self.lib.mtc_fused_backward_adam_enc_extra(
             C.byref(d), _p(sel.col_ptr), _p(sel.csc_row), _p(sel.csc_pos), _p(d_vals), _p(x_norm), _p(scale), _p(W_encT),
             _p(st_enc[0]), _p(st_enc[1]), _p(b_enc), _p(st_benc[0]), _p(st_benc[1]), C.byref(h_enc), _p(row_map),

@@ -96,7 +96,7 @@ class FusedAdam(torch.optim.Optimizer):
         if res.aux is not None and res.aux.get("dense") and res.d_vals is None:
             # dense aux branch: its gradient rows over the dead set (three GEMMs) ride into the fused kernels
             a = res.aux
-            extra = (a["dead"].row_map,) + tuple(hp.aux_extra_rows(a, res.x_norm))      # feature -> slot map made with the dead list
+            extra = (a["dead"].row_map,) + tuple(hp.aux_extra_rows(a, res.x_norm, side=tc._side_stream if two_streams else None))
         elif res.aux is not None:
             tc._join_csc()
             if two_streams:
@@ -138,7 +138,8 @@ class FusedAdam(torch.optim.Optimizer):
         hp.fused_backward_adam(res.desc, res.sel, res.g, res.d_vals, res.x_norm, None, tc.W_dec.data,
                                (sd["exp_avg"], sd["exp_avg_sq"]), W_encT.data, (m_e, v_e), tc.b_enc.data,
                                (sb["exp_avg"], sb["exp_avg_sq"]), hy["W_dec"], hy["W_enc"], hy["b_enc"],
-                               l1_term=float(tc.config["l1_coeff"]) / (res.desc.B * tc.total_dict_size), extra=extra)
+                               l1_term=float(tc.config["l1_coeff"]) / (res.desc.B * tc.total_dict_size), extra=extra,
+                               enc_wait=res.aux.get("enc_rows_event") if extra is not None else None)
         if e_b is not None:
             torch.cuda.current_stream().wait_event(e_b)     # every later reader of b_dec / g / the scalars is ordered behind the side stream
         else:

@@ -251,13 +251,25 @@ class MatryoshkaTranscoder(nn.Module):
             torch.cuda.current_stream().wait_event(ev)
             self._csc_event = None
 
-    def _aux_prepare(self, hp, d, aux_active: bool) -> bool:
+    def _aux_prepare(self, hp, d, aux_active: bool, side=None) -> bool:
         """Dense aux form: build the dead list (and read its length back) now, before the decode launch, so that the
-        host has a long kernel to queue the aux launches behind.  An empty list switches the branch off."""
+        host has a long kernel to queue the aux launches behind.  An empty list switches the branch off.
+        side: the stream the CSC build (which updates the counters) was issued on -- with a bound carried from the
+        previous forward nothing of the list is needed on the host, so the list is made there, behind the build and
+        underneath the decode launch; the aux branch joins it (self._dead_event) when it first reads the list."""
         self._aux_dead = None
+        self._dead_event = None
         bound, self._aux_bound = self._aux_bound, None
         if not aux_active or self.config.get("aux_mode", "gemm") != "gemm":
             return aux_active
+        if side is not None and bound:
+            with torch.cuda.stream(side):
+                dl = hp.aux_dead_list(d, self._cnt, float(self.config["n_batches_to_dead"]))
+                self._dead_event = torch.cuda.Event()
+                self._dead_event.record(side)
+            dl.cap = bound
+            self._aux_dead = dl
+            return True
         dl = hp.aux_dead_list(d, self._cnt, float(self.config["n_batches_to_dead"]))
         # launch sizes: the bound the previous forward's list left behind, else (first forward of an active stretch,
         # counters edited from outside) this list's own length, read back once
@@ -302,9 +314,13 @@ class MatryoshkaTranscoder(nn.Module):
         else:
             hp.build_csc(d, sel, self._cnt)
         self._dead_check_in -= 1
-        if self._dead_check_in <= 0:
+        # steady aux-active state on two streams: the previous list's bound sizes this forward's launches, so neither the
+        # check nor the list needs the host -- both stay on the side stream, behind the CSC build, under the decode launch
+        lagged = (self._two_streams and self._dead_check_in <= 0 and bool(self._aux_bound)
+                  and cfg.get("aux_mode", "gemm") == "gemm")
+        if self._dead_check_in <= 0 and not lagged:
             self._join_csc()                                         # the dead-feature check below reads the counters
-        aux_active = self._aux_prepare(hp, d, self._aux_may_be_active())
+        aux_active = self._aux_prepare(hp, d, self._aux_may_be_active(), side if lagged else None)
         x_hat, g, d_vals, row_stats, scalars, aux = self._decode_and_losses(
             hp, d, sel, acts, W_dec.contiguous(), b_dec.contiguous(), x_target, mean, std, need_grad, aux_active)
         from .engine import ForwardResult
@@ -331,6 +347,10 @@ class MatryoshkaTranscoder(nn.Module):
         aux_rows = None
         self._side_inputs = None
         if aux_active:
+            ev = getattr(self, "_dead_event", None)
+            if ev is not None:                                       # dead list made on the side stream (see _aux_prepare)
+                torch.cuda.current_stream().wait_event(ev)
+                self._dead_event = None
             aux, aux_rows = self._run_aux(hp, d, acts, sel, W_dec, x_target, x_hat, g, need_grad, l1_term)
             # g now carries the aux contribution; the fused step (defer) derives d a_bj from it inside the decoder-
             # gradient kernel when the aux branch is in its dense form, otherwise it is needed here
