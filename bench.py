@@ -270,12 +270,32 @@ def main():
     for i in range(args.warmup):
         step(i)
     fence()
+    # the dominant launch (the encoder) is timed LIVE: HIP events on its own stream around every 8th launch of the timed
+    # region, read after the closing fence (no synchronisation inside the region; an event pair costs the stream ~6 us, so
+    # every launch would take 0.8 % off the measured throughput, every 8th takes 0.1 %)
+    enc_events, enc_calls = [], [0]
+    hp_live = tc.hot_path()
+    enc_orig = hp_live.encode
+    if rank == 0 and world == 1 and not args.sharded:
+        def enc_timed(*a, **k):
+            enc_calls[0] += 1
+            if enc_calls[0] % 8 != 1:
+                return enc_orig(*a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = enc_orig(*a, **k)
+            e1.record()
+            enc_events.append((e0, e1))
+            return r
+        hp_live.encode = enc_timed
     n_dead_start = int((tc._cnt >= cfg["n_batches_to_dead"]).sum()) if args.aux_active else 0
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = step(i)
     fence()
     elapsed = time.perf_counter() - t0
+    hp_live.encode = enc_orig
+    enc_live_ms = sum(a.elapsed_time(b) for a, b in enc_events) / len(enc_events) if enc_events else None
     n_dead_end = int((tc._cnt >= cfg["n_batches_to_dead"]).sum()) if args.aux_active else 0
     if world > 1:
         import torch.distributed as dist
@@ -337,6 +357,12 @@ def main():
         # dominant KERNEL = longest single launch (the fused stage is two launches of one kernel template)
         per_launch = lambda n: kernels[n]["ms"] / (kernels[n]["launches"] or 1)
         dom = max((n for n in kernels if "bound" in kernels[n]), key=per_launch)
+        if dom == "encode" and enc_live_ms:
+            # the roofline block prices the average over the launches of the TIMED steps (the per-stage table below it comes
+            # from a separate single-stream pass of a few steps and moves a few per cent with the chip's power state)
+            ach = flop_enc / (enc_live_ms * 1e-3) / 1e12
+            kernels["encode"].update(ms=enc_live_ms, achieved=ach, frac=ach / kernels["encode"]["peak"],
+                                     ms_stage_pass=st["encode"], timed=f"HIP events around {len(enc_events)} launches of the timed steps (every 8th)")
         # HBM-side bytes per launch of that kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE,
         # profiles/README.md); only valid for the workload / dtype they were taken on
         traffic = None
