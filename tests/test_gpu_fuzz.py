@@ -97,3 +97,30 @@ def test_random_configuration_against_oracle(seed, gpu_lib):
                 assert float((got - ref).abs().max()) <= 2.0 * (i + 1) * cfg["lr"] + 2.0 ** -8 * float(ref.abs().max()), (seed, i, name)
     if cfg["n_batches_to_dead"] <= 3 and D >= 200:
         assert aux_steps > 0, "the scenario is meant to reach the auxiliary branch"
+    # a4 / a15 on the trained weights: eval-mode forward (threshold branch) and encode() / decode() on a 3-D batch,
+    # against the oracle's eval forward on the model's own parameters (sae.py:189-191, 363-406)
+    m.eval()
+    p_now = {k_: v.detach().cpu() for k_, v in m.state_dict().items()}
+    g = torch.Generator("cpu").manual_seed(seed * 100 + 99)
+    S = max(1, min(4, B))
+    xs3 = torch.randn(S, 3, A, generator=g).to(dt)
+    xs2, xt2 = xs3.reshape(-1, A), torch.randn(S * 3, A, generator=g).to(dt)
+    with torch.no_grad():
+        xn = hp.normalize(hp.desc(S * 3), xs2.to(DEV))[0] if cfg["input_unit_norm"] else xs2.to(DEV)
+        acts_gpu = hp.encode(hp.desc(S * 3), xn, m.W_enc.t(), m.b_enc).cpu()
+        out = m(xs2.to(DEV), xt2.to(DEV))
+        feats = m.encode(xs3.to(DEV))
+        recon = m.decode(feats.reshape(-1, D))
+    o, _, inter = R.forward(p_now, {"num_batches_not_active": m._cnt.cpu().clone()}, xs2, xt2, ocfg, training=False,
+                            acts_override=acts_gpu)
+    assert feats.shape == (S, 3, D)
+    dense = torch.zeros(S * 3 * D, dtype=dt)
+    dense[inter["flat_idx"]] = inter["vals"]
+    assert torch.equal(feats.reshape(-1).cpu(), dense), f"seed {seed}: eval encode()"
+    rt, at = tol(dt)
+    ref_out = o["transcoder_out"].float()
+    bar = (2e-5 if f32 else 4e-3) * max(1.0, float(ref_out.abs().max()))
+    _close(out["transcoder_out"].float().cpu(), ref_out, rt, bar, f"seed {seed}: eval forward")
+    _close(recon.float().cpu(), ref_out, rt, bar, f"seed {seed}: decode(encode(x))")
+    for name in ("loss", "l2_loss", "l0_norm", "fvu"):
+        _close(out[name].float(), o[name].float(), rt, at, f"seed {seed} eval {name}")
