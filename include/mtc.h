@@ -163,6 +163,42 @@ int mtc_select_offsets_sharded(const mtc_desc* d, const uint32_t* row_gt, const 
                                int32_t* row_ptr, uint32_t* tie_take, int64_t* minmax_out,
                                void* stream);
 int mtc_select_pack_minmax(const mtc_select_state* st, int64_t* out2, void* stream);
+
+/* The global batch-TopK of sae.py:176-187 over a FEATURE-SHARDED dictionary (the reference is single-process),
+ * in four phases with the caller's three fixed-shape collectives between them; nothing is read back.  The selection is
+ * the single-GPU one bit for bit whatever the number of shards: ties at tau are granted in ascending GLOBAL flat index
+ * (row, then feature = prefix group, shard, local feature).  d describes the LOCAL shard (d->D, d->prefix local).
+ *   begin  : zeroes the exchange buffers, inits st; bf16: one pass over acts keeps the entries >= the carried bound
+ *            (carry[0], as in mtc_select_global_topk_carry) in a compact matrix and histograms them into the 4096-bin
+ *            WINDOW xbuf[bin = key16 - bound16] + {xbuf[4096] candidates, xbuf[4097] overflowing rows}.
+ *            -> X1: all-reduce(SUM) of xbuf[0 .. 4104) as uint32.
+ *            fp32: init only; the caller then runs mtc_select_hist / all-reduce / mtc_select_scan per level on
+ *            xbuf + level * 4096 (xbuf holds mtc_select_sharded_xbuf_words() = 3 * 4096 words).
+ *   window : (bf16) the reduced window decides tau / the tie quota, or sets carry[1] = 0 (bound failed somewhere: too
+ *            few candidates globally, an overflowing row, tau in the clamped top bin); only then a second kernel fills
+ *            hist_full[32768] (the whole bf16 key space of the local activations).
+ *            -> X2: all-reduce(SUM) of hist_full (all zeros when the window served the call).
+ *   counts : (bf16, carry[1] == 0: tau from the reduced hist_full) then per row the entries > tau and, per prefix group,
+ *            the entries == tau -> pack[B * G + 1] (last word: the shard's smallest positive when fewer than k positives
+ *            exist globally, else ~0).  -> X3: all-gather of pack.
+ *   finish : row_ptr / tie quotas from all_pack [world][B * G + 1], st->nnz, threshold EMA (a5, sae.py:349-361) from the
+ *            GLOBAL smallest selected value (threshold may be NULL), the next call's bound, and the ordered fill.
+ * workspace: mtc_select_sharded_workspace_bytes(d), the SAME buffer for all four phases of one call. */
+size_t mtc_select_sharded_workspace_bytes(const mtc_desc* d);
+size_t mtc_select_sharded_xbuf_words(void);
+size_t mtc_select_sharded_full_bins(void);
+int mtc_select_sharded_begin(const mtc_desc* d, const void* acts, uint32_t k_total, void* workspace,
+                             size_t workspace_bytes, uint32_t* carry /* NULL for fp32 */, mtc_select_state* st,
+                             uint32_t* xbuf, uint32_t* hist_full /* NULL for fp32 */, uint32_t* pack, void* stream);
+int mtc_select_sharded_window(const mtc_desc* d, const void* acts, uint32_t k_total, uint32_t* carry,
+                              mtc_select_state* st, const uint32_t* xbuf, uint32_t* hist_full, void* stream);
+int mtc_select_sharded_counts(const mtc_desc* d, const void* acts, uint32_t k_total, void* workspace,
+                              const uint32_t* carry, mtc_select_state* st, const uint32_t* hist_full,
+                              uint32_t* pack, void* stream);
+int mtc_select_sharded_finish(const mtc_desc* d, const void* acts, void* workspace, uint32_t* carry,
+                              mtc_select_state* st, const uint32_t* all_pack, int32_t world, int32_t rank,
+                              int32_t* row_ptr, int32_t* col_idx, void* vals, void* threshold, float ema_lr,
+                              void* stream);
 int mtc_threshold_ema_global(const mtc_desc* d, const int64_t* minmax2, void* threshold, float lr,
                              void* stream);
 int mtc_shard_nnz_abs(const mtc_desc* d, const float* abs_rows, const mtc_select_state* st,
@@ -199,6 +235,14 @@ int mtc_decode_partial(const mtc_desc* d, const int32_t* row_ptr, const int32_t*
                        const void* vals, const void* W_dec, int32_t rows_per_shard,
                        float* partial_last, void* partial_pre,
                        float* abs_rows /* [B] sum |a| of the local entries, or NULL */, void* stream);
+/* The same for ONE ROW BLOCK of a batch that is decoded block by block (so that the reduce-scatter of block i runs beside
+ * the decode of block i+1): d->B = rows of the block, row_ptr / partial_last / abs_rows point at the block's first row
+ * (row_ptr holds absolute offsets), partial_pre at the block's slot of ONE exchange buffer
+ * [shard][block][G-1][rows_per_shard][A_t] whose shard stride (in elements) is pre_shard_stride (0 = dense). */
+int mtc_decode_partial_strided(const mtc_desc* d, const int32_t* row_ptr, const int32_t* col_idx,
+                               const void* vals, const void* W_dec, int32_t rows_per_shard,
+                               int64_t pre_shard_stride, float* partial_last, void* partial_pre,
+                               float* abs_rows, void* stream);
 /* mtc_decode_finish may be called in two parts so that the exchange of the earlier prefixes (FVU metrics only) can run
  * beside the backward kernels: partial_pre = NULL finishes the last prefix only (x_hat, g, its SSE row, the target
  * moments); partial_last = NULL (x_hat / g may be NULL) writes only the SSE rows of prefixes 0 .. G-2. */

@@ -55,11 +55,19 @@ PROTOTYPES = {
     "mtc_select_global_topk_carry_ema": (C.c_int, [DP, P, C.c_uint32, P, C.c_size_t, P, P, P, P, P, P, C.c_float, P]),
     "mtc_select_offsets_sharded": (C.c_int, [DP, P, P, C.c_int32, C.c_int32, C.c_int32, P, P, P, P, P]),
     "mtc_select_pack_minmax": (C.c_int, [P, P, P]),
+    "mtc_select_sharded_workspace_bytes": (C.c_size_t, [DP]),
+    "mtc_select_sharded_xbuf_words": (C.c_size_t, []),
+    "mtc_select_sharded_full_bins": (C.c_size_t, []),
+    "mtc_select_sharded_begin": (C.c_int, [DP, P, C.c_uint32, P, C.c_size_t, P, P, P, P, P, P]),
+    "mtc_select_sharded_window": (C.c_int, [DP, P, C.c_uint32, P, P, P, P, P]),
+    "mtc_select_sharded_counts": (C.c_int, [DP, P, C.c_uint32, P, P, P, P, P, P]),
+    "mtc_select_sharded_finish": (C.c_int, [DP, P, P, P, P, P, C.c_int32, C.c_int32, P, P, P, P, C.c_float, P]),
     "mtc_threshold_ema_global": (C.c_int, [DP, P, P, C.c_float, P]),
     "mtc_shard_nnz_abs": (C.c_int, [DP, P, P, P, P]),
     "mtc_threshold_ema": (C.c_int, [DP, P, P, C.c_float, P]),
     "mtc_decode_fwd": (C.c_int, [DP, P, P, P, P, P, P, P, P, P, P, P, P, P, C.c_float, P]),
     "mtc_decode_partial": (C.c_int, [DP, P, P, P, P, C.c_int32, P, P, P, P]),
+    "mtc_decode_partial_strided": (C.c_int, [DP, P, P, P, P, C.c_int32, C.c_int64, P, P, P, P]),
     "mtc_decode_finish": (C.c_int, [DP, C.c_int32, P, P, P, P, P, P, P, P, P, P, P]),
     "mtc_reduce_scalars": (C.c_int, [DP, P, P, P, P, C.c_int32, C.c_float, C.c_float, P, P]),
     "mtc_decode_bwd_vals": (C.c_int, [DP, P, P, P, P, C.c_float, P, P]),

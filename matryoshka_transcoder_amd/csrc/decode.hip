@@ -186,7 +186,7 @@ template <int DT, int NC>
 __global__ __launch_bounds__(256) void decode_partial_kernel(DecodeParams p, const int32_t* __restrict__ row_ptr,
                                                              const int32_t* __restrict__ col_idx,
                                                              const void* __restrict__ vals, const void* __restrict__ W_dec,
-                                                             int rps, float* __restrict__ partial_last,
+                                                             int rps, long long pre_shard_stride, float* __restrict__ partial_last,
                                                              void* __restrict__ partial_pre, float* __restrict__ abs_rows) {
     typedef DType<DT> D_;
     typedef typename D_::T T;
@@ -202,14 +202,16 @@ __global__ __launch_bounds__(256) void decode_partial_kernel(DecodeParams p, con
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc[c][k] = 0.f;
     // rows are grouped by the rank that will finish them (rps rows each) so that a reduce-scatter hands
-    // every rank one contiguous block: pre[(shard*(G-1) + gi)*rps + r], last[row] (already shard-major)
+    // every rank one contiguous block: pre[shard * pre_shard_stride + (gi * rps + r) * A_t], last[row] (already
+    // shard-major); pre_shard_stride = (G-1) * rps * A_t for one call over the whole batch, larger when the batch is
+    // decoded in row blocks that share one exchange buffer [shard][block][G-1][rps][A_t]
     const int shard = row / rps, r_in = row - shard * rps;
     auto flush = [&](int gi) {
 #pragma unroll
         for (int c = 0; c < NC; ++c)
             if (rc.valid(c)) {
                 if (gi == p.G - 1) store8<MTC_F32>(partial_last, (size_t)row * p.A_t + rc.off(c), acc[c]);
-                else store8<DT>(partial_pre, (((size_t)shard * (p.G - 1) + gi) * rps + r_in) * p.A_t + rc.off(c), acc[c]);
+                else store8<DT>(partial_pre, (size_t)shard * (size_t)pre_shard_stride + ((size_t)gi * rps + r_in) * p.A_t + rc.off(c), acc[c]);
             }
     };
     int gi = 0;
@@ -399,14 +401,24 @@ extern "C" int mtc_decode_bwd_vals(const mtc_desc* d, const int32_t* row_ptr, co
 extern "C" int mtc_decode_partial(const mtc_desc* d, const int32_t* row_ptr, const int32_t* col_idx, const void* vals,
                                   const void* W_dec, int32_t rows_per_shard, float* partial_last, void* partial_pre,
                                   float* abs_rows, void* stream) {
+    return mtc_decode_partial_strided(d, row_ptr, col_idx, vals, W_dec, rows_per_shard, 0, partial_last, partial_pre, abs_rows, stream);
+}
+
+extern "C" int mtc_decode_partial_strided(const mtc_desc* d, const int32_t* row_ptr, const int32_t* col_idx, const void* vals,
+                                          const void* W_dec, int32_t rows_per_shard, int64_t pre_shard_stride,
+                                          float* partial_last, void* partial_pre, float* abs_rows, void* stream) {
     if (check_desc(d, "mtc_decode_partial")) return -1;
+    const int64_t dense_stride = (int64_t)(d->G - 1) * rows_per_shard * d->A_t;
+    if (pre_shard_stride == 0) pre_shard_stride = dense_stride;
+    MTC_REQUIRE(pre_shard_stride >= dense_stride, "mtc_decode_partial: pre_shard_stride (%lld) < (G-1) * rows_per_shard * A_t (%lld)",
+                (long long)pre_shard_stride, (long long)dense_stride);
     MTC_REQUIRE(row_ptr && col_idx && vals && W_dec && partial_last && (partial_pre || d->G == 1),
                 "mtc_decode_partial: null pointer");
     MTC_REQUIRE(rows_per_shard > 0 && d->B % rows_per_shard == 0,
                 "mtc_decode_partial: rows_per_shard (%d) must divide B (%d)", rows_per_shard, d->B);
     const DecodeParams p = make_params(d, 0.f);
     DISPATCH_NC(d->dtype, nc_for(d->A_t), decode_partial_kernel, dim3((d->B + 3) / 4), dim3(256), as_stream(stream), p,
-                row_ptr, col_idx, vals, W_dec, rows_per_shard, partial_last, partial_pre, abs_rows);
+                row_ptr, col_idx, vals, W_dec, rows_per_shard, (long long)pre_shard_stride, partial_last, partial_pre, abs_rows);
     return check_launch("mtc_decode_partial");
 }
 

@@ -804,6 +804,315 @@ __global__ void threshold_ema_kernel(const mtc_select_state* __restrict__ st, vo
     D_::st(p, D_::rnd(a + b));
 }
 
+// ---------------------------------------------------------------- feature-sharded select with the carried bound
+// One process per GPU holds D / world features of every prefix group.  The exact global select needs three facts from
+// the other shards, each ONE collective of fixed shape (nothing is read back, no collective is conditional):
+//   X1  all-reduce of xbuf[4104]: a 4096-bin WINDOW histogram of this shard's candidates (entries >= the carried bound;
+//       bf16 keys have 15 bits, so bin = key16 - bound16 is EXACT: the scan of the reduced window yields tau itself, the
+//       count above it and the tie quota) + {candidates, rows that overflowed the compact matrix};
+//   X2  all-reduce of hist_full[32768]: the whole bf16 key space, filled ONLY when X1 says the bound failed somewhere
+//       (too few candidates globally, an overflowing row on any shard, tau in the clamped top bin) -- all zeros otherwise;
+//   X3  all-gather of pack[B*G + 1]: per (row, prefix group) counts of entries equal to tau (+ the shard's smallest
+//       positive value when fewer than k positives exist), from which every shard grants the ties in ascending GLOBAL flat
+//       index (row, then feature: group, shard, local feature) -- the order of the single-GPU select, so the selection
+//       does not depend on the number of shards.
+// Granting in that order is a prefix of every shard's local (row, column) order of ties, so one number per row
+// (tie_take) still describes it and the ordered fill is the single-GPU kernel.
+constexpr int WIN_BINS = 4096;
+constexpr int FULL_BINS = 32768;
+constexpr int XBUF_WORDS = 3 * HIST_BINS;          // window + 2 counters (bf16), or the three level histograms (fp32)
+
+struct GroupBounds { int G; int prefix[MTC_MAX_PREFIX]; };
+
+__global__ __launch_bounds__(1024) void shard_select_init_kernel(mtc_select_state* st, uint32_t k_total, uint32_t* xbuf,
+                                                                 uint32_t* hist_full, uint32_t* pack_min) {
+    const int t = threadIdx.x;
+    for (int i = t; i < XBUF_WORDS; i += 1024) xbuf[i] = 0;
+    if (hist_full) for (int i = t; i < FULL_BINS; i += 1024) hist_full[i] = 0;
+    if (t == 0) {
+        st->key_prefix = 0; st->k_rem = k_total; st->all_pos = 0; st->n_gt = 0;
+        st->tau_bits = 0; st->n_tie_take = 0; st->min_sel_bits = 0xffffffffu; st->nnz = 0;
+        for (int i = 0; i < 8; ++i) st->pad[i] = 0;
+        *pack_min = 0xffffffffu;
+    }
+}
+
+// window histogram of the compact candidate matrix (bf16): a workgroup walks rows blockIdx.x, + gridDim.x, ...; only the
+// filled part of a row is read (cand_cnt).  Block 0 also leaves {candidates, overflowing rows} behind the window.
+__global__ __launch_bounds__(256) void shard_window_hist_kernel(const u16* __restrict__ cand_vals, const uint32_t* __restrict__ cand_cnt,
+                                                                int B, int C, const uint32_t* __restrict__ carry,
+                                                                uint32_t* __restrict__ xbuf) {
+    __shared__ uint32_t lh[WIN_BINS];
+    __shared__ uint32_t s_tot[4], s_over[4];
+    const uint32_t guess = carry[0];
+    if (guess == 0) return;                             // no bound: the candidate pass did not run (uniform)
+    const uint32_t g16 = guess >> 16;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < WIN_BINS; i += 256) lh[i] = 0;
+    __syncthreads();
+    for (int row = blockIdx.x * 4 + w; row < B; row += gridDim.x * 4) {
+        const int n = min((int)cand_cnt[row], C);
+        const u16* src = cand_vals + (size_t)row * C;
+        for (int c = lane; c * 8 < n; c += 64) {
+            const u32x4 r = *reinterpret_cast<const u32x4*>(src + (size_t)c * 8);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const uint32_t k16 = h ? (r[i] >> 16) : (r[i] & 0xffffu);
+                    if (k16 >= g16 && k16 <= 0x7f80u) atomicAdd(&lh[min(k16 - g16, (uint32_t)WIN_BINS - 1)], 1u);   // (0 = padding)
+                }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < WIN_BINS; i += 256) {
+        const uint32_t v = lh[i];
+        if (v) atomicAdd(&xbuf[i], v);
+    }
+    if (blockIdx.x == 0) {
+        uint32_t tot = 0, over = 0;
+        for (int r = threadIdx.x; r < B; r += 256) { const uint32_t n = cand_cnt[r]; tot += n; over += n > (uint32_t)C ? 1u : 0u; }
+        tot = wave_sum_u32(tot); over = wave_sum_u32(over);
+        if (lane == 0) { s_tot[w] = tot; s_over[w] = over; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            xbuf[WIN_BINS] = s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
+            xbuf[WIN_BINS + 1] = s_over[0] + s_over[1] + s_over[2] + s_over[3];
+        }
+    }
+}
+
+// suffix scan of `nbins` reduced bins by one workgroup of 1024 threads (nbins a multiple of 1024): the bin that holds the
+// k-th largest entry, and the count above it.  Returns through shared memory; found_bin = ~0 when the bins hold fewer than k.
+template <int PER>
+__device__ __forceinline__ void suffix_find(const uint32_t* __restrict__ hist, uint32_t k, uint32_t* part /*[1024]*/,
+                                            uint32_t* found /*[3]: bin, above, total*/) {
+    const int t = threadIdx.x;
+    uint32_t hs[PER], mine = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) { hs[i] = hist[PER * t + i]; mine += hs[i]; }
+    part[t] = mine;
+    if (t == 0) { found[0] = 0xffffffffu; found[1] = 0; }
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const uint32_t add = (t + off < 1024) ? part[t + off] : 0u;
+        __syncthreads();
+        part[t] += add;
+        __syncthreads();
+    }
+    uint32_t above = (t + 1 < 1024) ? part[t + 1] : 0u;
+#pragma unroll
+    for (int i = PER - 1; i >= 0; --i) {
+        if (above < k && k <= above + hs[i]) { found[0] = PER * t + i; found[1] = above; }
+        above += hs[i];
+    }
+    if (t == 0) found[2] = part[0];
+    __syncthreads();
+}
+
+// after X1: is the carried bound valid everywhere?  If so tau / n_gt / the tie quota follow from the window.
+__global__ __launch_bounds__(1024) void shard_window_scan_kernel(const uint32_t* __restrict__ xbuf, uint32_t k_total,
+                                                                 uint32_t* carry, mtc_select_state* st) {
+    __shared__ uint32_t part[1024];
+    __shared__ uint32_t found[3];
+    suffix_find<WIN_BINS / 1024>(xbuf, k_total, part, found);
+    if (threadIdx.x != 0) return;
+    const uint32_t guess = carry[0], tot = xbuf[WIN_BINS], over = xbuf[WIN_BINS + 1];
+    // (the clamped top bin mixes values: a tau in it cannot be told from the window)
+    const uint32_t ok = (guess != 0 && over == 0 && tot >= k_total && k_total > 0 && found[0] != 0xffffffffu &&
+                         found[0] < (uint32_t)WIN_BINS - 1 && found[2] == tot) ? 1u : 0u;
+    if (ok) {
+        const uint32_t tau = ((guess >> 16) + found[0]) << 16;
+        st->key_prefix = tau; st->tau_bits = tau; st->n_gt = found[1];
+        st->k_rem = k_total - found[1]; st->n_tie_take = k_total - found[1]; st->all_pos = 0;
+    }
+    carry[1] = ok; carry[2] = tot; carry[3] = over;
+    carry[4] += ok; carry[5] += 1u - ok;
+}
+
+// fallback (flag == 0 only): the whole bf16 key space of this shard's activations, 128 KiB of LDS bins per workgroup
+__global__ __launch_bounds__(256) void shard_full_hist_bf16_kernel(const u16* __restrict__ acts, size_t n_chunks,
+                                                                   const uint32_t* __restrict__ flag,
+                                                                   uint32_t* __restrict__ hist_full) {
+    extern __shared__ uint32_t lhf[];
+    if (*flag != 0) return;                             // uniform: the window served this call
+    for (int i = threadIdx.x; i < FULL_BINS; i += 256) lhf[i] = 0;
+    __syncthreads();
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t c = (size_t)blockIdx.x * 256 + threadIdx.x; c < n_chunks; c += stride) {
+        const u32x4 r = *reinterpret_cast<const u32x4*>(acts + c * 8);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t k16 = h ? (r[i] >> 16) : (r[i] & 0xffffu);
+                if (k16 != 0 && k16 <= 0x7f80u) atomicAdd(&lhf[k16], 1u);
+            }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < FULL_BINS; i += 256) {
+        const uint32_t v = lhf[i];
+        if (v) atomicAdd(&hist_full[i], v);
+    }
+}
+
+// after X2 (flag == 0 only): tau from the reduced full histogram, or "every positive is selected"
+__global__ __launch_bounds__(1024) void shard_full_scan_kernel(const uint32_t* __restrict__ hist_full, uint32_t k_total,
+                                                               const uint32_t* __restrict__ flag, mtc_select_state* st) {
+    __shared__ uint32_t part[1024];
+    __shared__ uint32_t found[3];
+    if (*flag != 0) return;                             // uniform
+    suffix_find<FULL_BINS / 1024>(hist_full, k_total, part, found);
+    if (threadIdx.x != 0) return;
+    if (found[0] == 0xffffffffu) {
+        st->all_pos = 1; st->n_gt = found[2]; st->tau_bits = 0; st->n_tie_take = 0; st->k_rem = 0; st->key_prefix = 0;
+    } else {
+        const uint32_t tau = found[0] << 16;
+        st->key_prefix = tau; st->tau_bits = tau; st->n_gt = found[1];
+        st->k_rem = k_total - found[1]; st->n_tie_take = k_total - found[1]; st->all_pos = 0;
+    }
+}
+
+// wave per row: entries > tau (row_gt) and entries == tau per prefix group (pack[row * G + g]); reads the compact
+// candidate matrix (+ its column map) when *flag == 1, the activations otherwise (flag == null: always the activations).
+template <int DT>
+__global__ __launch_bounds__(256) void shard_group_counts_kernel(const void* __restrict__ cand_vals, const int32_t* __restrict__ cand_cols,
+                                                                 int C, const void* __restrict__ acts_full, int B, int D, GroupBounds gb,
+                                                                 const mtc_select_state* __restrict__ st,
+                                                                 const uint32_t* __restrict__ flag, uint32_t* __restrict__ row_gt,
+                                                                 uint32_t* __restrict__ pack) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B) return;
+    const bool compact = flag && *flag == 1;            // uniform
+    const void* __restrict__ src = compact ? cand_vals : acts_full;
+    const int cols = compact ? C : D;
+    const bool all_pos = st->all_pos != 0;
+    const float tau = all_pos ? 0.f : __uint_as_float(st->tau_bits);
+    const size_t base = (size_t)row * cols;
+    uint32_t gt = 0, mn = 0xffffffffu;
+    uint32_t eq[MTC_MAX_PREFIX];
+#pragma unroll
+    for (int q = 0; q < MTC_MAX_PREFIX; ++q) eq[q] = 0;
+    const int nch = cols >> 3;
+    for (int c0 = lane; c0 < nch; c0 += 256) {
+        Raw<DT> r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (c0 + 64 * u < nch) r[u] = load_raw<DT>(src, base + (size_t)(c0 + 64 * u) * 8);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (c0 + 64 * u >= nch) break;
+            float v[8];
+            unpack(r[u], v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (v[i] > tau) { ++gt; mn = min(mn, __float_as_uint(v[i])); }
+                else if (!all_pos && v[i] == tau) {
+                    const size_t at = base + (size_t)(c0 + 64 * u) * 8 + i;
+                    const int col = compact ? cand_cols[at] : (c0 + 64 * u) * 8 + i;
+                    int g = 0;
+                    for (int q = 0; q + 1 < gb.G; ++q) g += col >= gb.prefix[q] ? 1 : 0;
+#pragma unroll
+                    for (int q = 0; q < MTC_MAX_PREFIX; ++q) eq[q] += (g == q) ? 1u : 0u;
+                }
+            }
+        }
+    }
+    gt = wave_sum_u32(gt);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, o, 64));
+    for (int q = 0; q < gb.G; ++q) {
+        uint32_t e = 0;
+#pragma unroll
+        for (int z = 0; z < MTC_MAX_PREFIX; ++z) e = z == q ? eq[z] : e;
+        e = wave_sum_u32(e);
+        if (lane == 0) pack[(size_t)row * gb.G + q] = e;
+    }
+    if (lane == 0) {
+        row_gt[row] = gt;
+        // only "every positive is selected" needs the smallest positive (with a tau the smallest selected value is tau)
+        if (all_pos && mn != 0xffffffffu) atomicMin(&pack[(size_t)B * gb.G], mn);
+    }
+}
+
+// one workgroup, after X3: CSR offsets + per-row tie quota in ascending GLOBAL flat index, the threshold EMA from the
+// global smallest selected value, and the next call's bound.  all_pack [world][B * G + 1].
+template <int DT>
+__global__ __launch_bounds__(1024) void shard_offsets_groups_kernel(int B, int G, const uint32_t* __restrict__ row_gt,
+                                                                    const uint32_t* __restrict__ all_pack, int world, int rank,
+                                                                    mtc_select_state* st, int32_t* __restrict__ row_ptr,
+                                                                    uint32_t* __restrict__ tie_take, uint32_t* carry,
+                                                                    void* threshold, float lr) {
+    __shared__ uint32_t sm[16];
+    const int t = threadIdx.x;
+    const int per = (B + 1023) / 1024;
+    const int r0 = min(B, t * per), r1 = min(B, r0 + per);
+    const size_t stride = (size_t)B * G + 1;
+    const uint32_t quota = st->all_pos ? 0u : st->n_tie_take;
+    uint32_t my_eq = 0;
+    for (int r = r0; r < r1; ++r)
+        for (int w = 0; w < world; ++w)
+            for (int g = 0; g < G; ++g) my_eq += all_pack[(size_t)w * stride + (size_t)r * G + g];
+    uint32_t tot;
+    uint32_t run = block_excl_scan_1024(my_eq, sm, &tot);      // ties in earlier rows (every shard, every group)
+    uint32_t my_nnz = 0;
+    for (int r = r0; r < r1; ++r) {
+        uint32_t take = 0;
+        for (int g = 0; g < G; ++g) {
+            uint32_t grp_tot = 0, earlier = 0;
+            for (int w = 0; w < world; ++w) {
+                const uint32_t e = all_pack[(size_t)w * stride + (size_t)r * G + g];
+                grp_tot += e;
+                if (w < rank) earlier += e;
+            }
+            const uint32_t mine = all_pack[(size_t)rank * stride + (size_t)r * G + g];
+            const uint32_t before = run + earlier;             // global flat order: row, group, shard, local feature
+            take += before >= quota ? 0u : min(mine, quota - before);
+            run += grp_tot;
+        }
+        tie_take[r] = take;
+        my_nnz += row_gt[r] + take;
+    }
+    uint32_t nnz_total;
+    uint32_t base = block_excl_scan_1024(my_nnz, sm, &nnz_total);
+    for (int r = r0; r < r1; ++r) {
+        row_ptr[r] = (int32_t)base;
+        base += row_gt[r] + tie_take[r];
+    }
+    if (t != 0) return;
+    row_ptr[B] = (int32_t)nnz_total;
+    st->nnz = nnz_total;
+    // global smallest selected value: tau when one exists (the k-th largest entry is selected somewhere), else the
+    // smallest positive over the shards
+    uint32_t gmin = 0xffffffffu;
+    bool any;
+    if (st->all_pos) {
+        for (int w = 0; w < world; ++w) gmin = min(gmin, all_pack[(size_t)w * stride + (size_t)B * G]);
+        any = st->n_gt > 0;
+    } else {
+        gmin = st->tau_bits;
+        any = st->n_gt + st->n_tie_take > 0;
+    }
+    st->min_sel_bits = gmin;
+    if (threshold && any && gmin != 0xffffffffu) {
+        typedef DType<DT> D_;
+        typedef typename D_::T T;
+        T* p = reinterpret_cast<T*>(threshold);
+        const float thr = D_::ld(p);
+        const float a = D_::rnd((float)(1.0 - (double)lr) * thr);
+        const float b = D_::rnd(lr * __uint_as_float(gmin));
+        D_::st(p, D_::rnd(a + b));
+    }
+    if (carry) {
+        // the same on every shard: derived from global quantities only
+        const uint32_t margin = 8u << 16;
+        uint32_t g = 0;
+        if (!st->all_pos && any && st->tau_bits > margin + 0x00800000u && st->tau_bits <= 0x7f800000u) g = st->tau_bits - margin;
+        carry[0] = g;
+    }
+}
+
 template <int DT>
 __global__ __launch_bounds__(256) void densify_kernel(const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col_idx,
                                                       const void* __restrict__ vals, int B, int D, int max_col,
@@ -1069,6 +1378,124 @@ extern "C" int mtc_select_offsets_sharded(const mtc_desc* d, const uint32_t* row
     hipLaunchKernelGGL(select_offsets_sharded_kernel, dim3(1), dim3(1024), 0, as_stream(stream), d->B, row_gt, all_eq, eq_stride,
                        world, rank, st, row_ptr, tie_take, reinterpret_cast<long long*>(minmax_out));
     return check_launch("mtc_select_offsets_sharded");
+}
+
+// ---- feature-sharded select in four phases (collectives X1 / X2 / X3 of the caller between them; see the kernels)
+namespace {
+struct ShardWs {
+    uint32_t *row_gt, *tie_take, *cand_cnt;
+    char* cand_vals;
+    int32_t* cand_cols;
+    int C;
+};
+size_t shard_ws_layout(const mtc_desc* d, char* base, ShardWs* out) {
+    const size_t es = d->dtype == MTC_BF16 ? 2 : 4;
+    const size_t bpad = ((size_t)d->B + 63) & ~(size_t)63;
+    const int C = carry_cols(d);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
+    const size_t o_gt = take(bpad * 4), o_tt = take(bpad * 4), o_cnt = take(bpad * 4);
+    const size_t o_cv = take((size_t)d->B * C * es), o_cc = take((size_t)d->B * C * 4);
+    if (out) {
+        out->row_gt = reinterpret_cast<uint32_t*>(base + o_gt);
+        out->tie_take = reinterpret_cast<uint32_t*>(base + o_tt);
+        out->cand_cnt = reinterpret_cast<uint32_t*>(base + o_cnt);
+        out->cand_vals = base + o_cv;
+        out->cand_cols = reinterpret_cast<int32_t*>(base + o_cc);
+        out->C = C;
+    }
+    return off;
+}
+GroupBounds group_bounds(const mtc_desc* d) {
+    GroupBounds gb;
+    gb.G = d->G;
+    for (int i = 0; i < MTC_MAX_PREFIX; ++i) gb.prefix[i] = i < d->G ? d->prefix[i] : 0x7fffffff;
+    return gb;
+}
+}  // namespace
+
+extern "C" size_t mtc_select_sharded_workspace_bytes(const mtc_desc* d) { return d ? shard_ws_layout(d, nullptr, nullptr) : 0; }
+extern "C" size_t mtc_select_sharded_xbuf_words(void) { return XBUF_WORDS; }
+extern "C" size_t mtc_select_sharded_full_bins(void) { return FULL_BINS; }
+
+extern "C" int mtc_select_sharded_begin(const mtc_desc* d, const void* acts, uint32_t k_total, void* workspace,
+                                        size_t workspace_bytes, uint32_t* carry, mtc_select_state* st, uint32_t* xbuf,
+                                        uint32_t* hist_full, uint32_t* pack, void* stream) {
+    if (check_desc(d, "mtc_select_sharded_begin")) return -1;
+    MTC_REQUIRE(acts && workspace && st && xbuf && pack, "mtc_select_sharded_begin: null pointer");
+    MTC_REQUIRE(workspace_bytes >= mtc_select_sharded_workspace_bytes(d), "mtc_select_sharded_begin: workspace too small (%zu < %zu)",
+                workspace_bytes, mtc_select_sharded_workspace_bytes(d));
+    MTC_REQUIRE(d->dtype != MTC_BF16 || (carry && hist_full), "mtc_select_sharded_begin: bf16 needs carry and hist_full");
+    hipStream_t s = as_stream(stream);
+    ShardWs w;
+    shard_ws_layout(d, reinterpret_cast<char*>(workspace), &w);
+    hipLaunchKernelGGL(shard_select_init_kernel, dim3(1), dim3(1024), 0, s, st, k_total, xbuf,
+                       d->dtype == MTC_BF16 ? hist_full : nullptr, pack + (size_t)d->B * d->G);
+    if (d->dtype == MTC_BF16) {
+        // one pass over the activations with the carried bound, then the window histogram of what it kept
+        hipLaunchKernelGGL(select_candidates_kernel<MTC_BF16>, dim3((d->B + 3) / 4), dim3(256), 0, s, acts, d->B, d->D, w.C,
+                           (const uint32_t*)carry, (void*)w.cand_vals, w.cand_cols, w.cand_cnt);
+        hipLaunchKernelGGL(shard_window_hist_kernel, dim3(std::min(256, (d->B + 3) / 4)), dim3(256), 0, s,
+                           (const u16*)w.cand_vals, (const uint32_t*)w.cand_cnt, d->B, w.C, (const uint32_t*)carry, xbuf);
+    }
+    return check_launch("mtc_select_sharded_begin");
+}
+
+extern "C" int mtc_select_sharded_window(const mtc_desc* d, const void* acts, uint32_t k_total, uint32_t* carry,
+                                         mtc_select_state* st, const uint32_t* xbuf, uint32_t* hist_full, void* stream) {
+    if (check_desc(d, "mtc_select_sharded_window")) return -1;
+    MTC_REQUIRE(d->dtype == MTC_BF16, "mtc_select_sharded_window: bf16 only (fp32 runs the three histogram levels)");
+    MTC_REQUIRE(acts && carry && st && xbuf && hist_full, "mtc_select_sharded_window: null pointer");
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(shard_window_scan_kernel, dim3(1), dim3(1024), 0, s, xbuf, k_total, carry, st);
+    static bool attr_done[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
+    if (dev < 0 || !attr_done[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(shard_full_hist_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                FULL_BINS * 4) == hipSuccess && dev >= 0) attr_done[dev] = true;
+    }
+    const size_t n_chunks = (size_t)d->B * d->D / 8;
+    const int grid = (int)std::max<size_t>(1, std::min<size_t>((n_chunks + 256 * 64 - 1) / (256 * 64), 256));
+    hipLaunchKernelGGL(shard_full_hist_bf16_kernel, dim3(grid), dim3(256), FULL_BINS * 4, s, (const u16*)acts, n_chunks,
+                       (const uint32_t*)(carry + 1), hist_full);
+    return check_launch("mtc_select_sharded_window");
+}
+
+extern "C" int mtc_select_sharded_counts(const mtc_desc* d, const void* acts, uint32_t k_total, void* workspace,
+                                         const uint32_t* carry, mtc_select_state* st, const uint32_t* hist_full,
+                                         uint32_t* pack, void* stream) {
+    if (check_desc(d, "mtc_select_sharded_counts")) return -1;
+    MTC_REQUIRE(acts && workspace && st && pack, "mtc_select_sharded_counts: null pointer");
+    MTC_REQUIRE(d->dtype != MTC_BF16 || (carry && hist_full), "mtc_select_sharded_counts: bf16 needs carry and hist_full");
+    hipStream_t s = as_stream(stream);
+    ShardWs w;
+    shard_ws_layout(d, reinterpret_cast<char*>(workspace), &w);
+    const uint32_t* flag = d->dtype == MTC_BF16 ? carry + 1 : nullptr;
+    if (flag) hipLaunchKernelGGL(shard_full_scan_kernel, dim3(1), dim3(1024), 0, s, hist_full, k_total, flag, st);
+    DISPATCH_DT(d->dtype, shard_group_counts_kernel, dim3((d->B + 3) / 4), dim3(256), 0, s, (const void*)w.cand_vals,
+                (const int32_t*)w.cand_cols, w.C, acts, d->B, d->D, group_bounds(d), (const mtc_select_state*)st, flag, w.row_gt, pack);
+    return check_launch("mtc_select_sharded_counts");
+}
+
+extern "C" int mtc_select_sharded_finish(const mtc_desc* d, const void* acts, void* workspace, uint32_t* carry,
+                                         mtc_select_state* st, const uint32_t* all_pack, int32_t world, int32_t rank,
+                                         int32_t* row_ptr, int32_t* col_idx, void* vals, void* threshold, float ema_lr,
+                                         void* stream) {
+    if (check_desc(d, "mtc_select_sharded_finish")) return -1;
+    MTC_REQUIRE(acts && workspace && st && all_pack && row_ptr && col_idx && vals, "mtc_select_sharded_finish: null pointer");
+    MTC_REQUIRE(world >= 1 && rank >= 0 && rank < world, "mtc_select_sharded_finish: bad rank %d of %d", rank, world);
+    MTC_REQUIRE(d->dtype != MTC_BF16 || carry, "mtc_select_sharded_finish: bf16 needs carry");
+    hipStream_t s = as_stream(stream);
+    ShardWs w;
+    shard_ws_layout(d, reinterpret_cast<char*>(workspace), &w);
+    uint32_t* cr = d->dtype == MTC_BF16 ? carry : nullptr;
+    DISPATCH_DT(d->dtype, shard_offsets_groups_kernel, dim3(1), dim3(1024), 0, s, d->B, d->G, (const uint32_t*)w.row_gt, all_pack,
+                world, rank, st, row_ptr, w.tie_take, cr, threshold, ema_lr);
+    int rc;
+    if ((rc = check_launch("mtc_select_sharded_finish"))) return rc;
+    if (cr) return fill_impl(d, w.C, w.cand_vals, st, nullptr, row_ptr, w.tie_take, col_idx, vals, w.cand_cols, cr + 1, 1, stream, acts, d->D);
+    return fill_impl(d, d->D, acts, st, nullptr, row_ptr, w.tie_take, col_idx, vals, nullptr, nullptr, 0, stream);
 }
 
 extern "C" int mtc_select_pack_minmax(const mtc_select_state* st, int64_t* out2, void* stream) {

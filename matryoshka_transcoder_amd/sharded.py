@@ -71,16 +71,42 @@ class ShardLayout:
         return torch.argsort(order)
 
 
-def tie_before(all_eq: torch.Tensor, rank: int) -> torch.Tensor:
-    """all_eq [world, B] = per-row counts of activations equal to tau on every rank.  Ties are granted
-    in (row, rank) order; returns, for `rank`, how many ties precede each of its rows."""
-    per_row = all_eq.sum(0)
-    earlier_rows = torch.cumsum(per_row, 0) - per_row
-    earlier_ranks = all_eq[:rank].sum(0) if rank > 0 else torch.zeros_like(per_row)
-    return (earlier_rows + earlier_ranks).to(torch.int32)
+def tie_take_global_order(all_eq: torch.Tensor, quota: int, rank: int) -> torch.Tensor:
+    """Host restatement of the tie grant of mtc_select_sharded_finish (tests; the step itself runs the kernel).
+    all_eq [world, B, G] = per (row, prefix group) counts of activations equal to tau on every rank.  Ties are granted
+    in ascending GLOBAL flat index -- row, then feature, and the global feature order inside a row is (group, rank,
+    local feature) because rank r owns slice r of every group -- until `quota` are taken.  Returns, for `rank`, how
+    many of its ties are taken in every row [B] (a prefix of the row's local ties: the grant is monotone in the order)."""
+    W, B, G = all_eq.shape
+    flat = all_eq.permute(1, 2, 0).reshape(-1).to(torch.int64)            # (row, group, rank) order
+    before = torch.cumsum(flat, 0) - flat
+    take = torch.minimum((quota - before).clamp_min(0), flat)
+    return take.reshape(B, G, W)[:, :, rank].sum(1).to(torch.int32)
 
 
-class _Comm:
+class _CommBase:
+    """What the sharded step needs from a transport.  Collectives run on torch's CURRENT stream; `stream` is a second
+    stream of this object on which the step issues the exchanges that run beside kernels of the main stream.  With
+    `timing` set to a dict, every collective is bracketed by HIP events on the stream it runs on
+    (name -> [(start, end, payload bytes)]; bench.py reads them after its fence)."""
+    timing = None
+    _cstream = None
+
+    def comm_stream(self, device) -> "torch.cuda.Stream":
+        if self._cstream is None:
+            self._cstream = torch.cuda.Stream(device=device)
+        return self._cstream
+
+    def _timed(self, tag, nbytes):
+        if self.timing is None or tag is None:
+            return None
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self.timing.setdefault(tag, []).append((e0, e1, int(nbytes)))
+        return e1
+
+
+class _Comm(_CommBase):
     """torch.distributed on device tensors.  backend "nccl" is RCCL on ROCm; with "gloo" (tests)
     device tensors are staged through the host."""
 
@@ -90,69 +116,63 @@ class _Comm:
         self.rank = dist.get_rank(group)
         self.staged = dist.get_backend(group) == "gloo"
 
-    def all_reduce(self, t: torch.Tensor, op=dist.ReduceOp.SUM) -> torch.Tensor:
+    def all_reduce(self, t: torch.Tensor, op=dist.ReduceOp.SUM, tag=None) -> torch.Tensor:
+        e = self._timed(tag, t.numel() * t.element_size())
         if self.staged and t.is_cuda:
             h = t.cpu()
             dist.all_reduce(h, op=op, group=self.group)
             t.copy_(h)
         else:
             dist.all_reduce(t, op=op, group=self.group)
+        if e is not None:
+            e.record()
         return t
 
-    def reduce_scatter(self, t: torch.Tensor) -> torch.Tensor:
-        """Sum over ranks of t [world * n, ...]; returns this rank's block [n, ...]."""
-        n = t.shape[0] // self.world
+    def reduce_scatter_into(self, out: torch.Tensor, t: torch.Tensor, tag=None) -> torch.Tensor:
+        """out (contiguous, numel = t.numel() / world) = this rank's block of the sum over ranks of t (contiguous)."""
+        e = self._timed(tag, t.numel() * t.element_size())
         if self.staged:
             h = t.float().cpu() if t.is_cuda else t.float()
             dist.all_reduce(h, group=self.group)
-            return h[self.rank * n:(self.rank + 1) * n].to(device=t.device, dtype=t.dtype)
-        out = torch.empty((n,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        dist.reduce_scatter_tensor(out, t.contiguous(), group=self.group)
+            n = out.numel()
+            out.copy_(h.reshape(-1)[self.rank * n:(self.rank + 1) * n].reshape(out.shape).to(out.dtype))
+        else:
+            dist.reduce_scatter_tensor(out, t, group=self.group)
+        if e is not None:
+            e.record()
         return out
 
-    def reduce_scatter_begin(self, t: torch.Tensor):
-        """reduce_scatter that runs beside whatever the caller enqueues next (RCCL: on the process group's own stream);
-        reduce_scatter_end() makes the current stream wait for it and returns this rank's block."""
-        if self.staged:
-            return (None, self.reduce_scatter(t), None)
-        n = t.shape[0] // self.world
-        t = t.contiguous()
-        out = torch.empty((n,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        work = dist.reduce_scatter_tensor(out, t, group=self.group, async_op=True)
-        return (work, out, t)                                  # operands stay referenced until the wait
-
-    @staticmethod
-    def reduce_scatter_end(handle) -> torch.Tensor:
-        work, out, _ = handle
-        if work is not None:
-            work.wait()                                        # stream-level wait: the host does not block
-        return out
-
-    def all_gather_begin(self, t: torch.Tensor):
-        """all_gather that runs beside whatever the caller enqueues next (see reduce_scatter_begin); all_gather_end()
-        makes the current stream wait for it and returns [world, ...]."""
-        if self.staged:
-            return (None, self.all_gather(t), None)
-        t = t.contiguous()
-        out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        work = dist.all_gather_into_tensor(out, t, group=self.group, async_op=True)
-        return (work, out.reshape((self.world,) + tuple(t.shape)), t)
-
-    all_gather_end = reduce_scatter_end
-
-    def all_gather(self, t: torch.Tensor) -> torch.Tensor:
+    def all_gather_into(self, out: torch.Tensor, t: torch.Tensor, tag=None) -> torch.Tensor:
+        """out (contiguous, numel = world * t.numel()) = the ranks' t (contiguous) one after the other."""
+        e = self._timed(tag, out.numel() * out.element_size())
         if self.staged and t.is_cuda:
             h = t.cpu()
-            out = [torch.empty_like(h) for _ in range(self.world)]
-            dist.all_gather(out, h, group=self.group)
-            return torch.stack(out).to(t.device)
+            parts = [torch.empty_like(h) for _ in range(self.world)]
+            dist.all_gather(parts, h, group=self.group)
+            out.copy_(torch.stack(parts).reshape(out.shape))
+        elif self.staged:
+            parts = [torch.empty_like(t) for _ in range(self.world)]
+            dist.all_gather(parts, t, group=self.group)
+            out.copy_(torch.stack(parts).reshape(out.shape))
+        else:
+            dist.all_gather_into_tensor(out, t, group=self.group)
+        if e is not None:
+            e.record()
+        return out
+
+    def reduce_scatter(self, t: torch.Tensor, tag=None) -> torch.Tensor:
+        """Sum over ranks of t [world * n, ...]; returns this rank's block [n, ...]."""
+        n = t.shape[0] // self.world
+        out = torch.empty((n,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        return self.reduce_scatter_into(out, t.contiguous(), tag)
+
+    def all_gather(self, t: torch.Tensor, tag=None) -> torch.Tensor:
         t = t.contiguous()
-        out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        dist.all_gather_into_tensor(out, t, group=self.group)
-        return out.reshape((self.world,) + tuple(t.shape))
+        out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        return self.all_gather_into(out, t, tag)
 
 
-class _LibComm:
+class _LibComm(_CommBase):
     """The same exchanges through libmtc's own RCCL wrappers (mtc_comm_*, include/mtc.h): ctypes calls on torch's current
     stream, no torch.distributed on the data path (it only hands the 128-byte unique id round once).  Opt-in
     (cfg["comm"] = "libmtc"): a collective then costs the host one ctypes call, which matters where the sharded step is
@@ -189,42 +209,44 @@ class _LibComm:
         except KeyError:
             raise _lib.MtcError(f"mtc_comm: unsupported dtype {t.dtype}") from None
 
-    def all_reduce(self, t: torch.Tensor, op=dist.ReduceOp.SUM) -> torch.Tensor:
+    def all_reduce(self, t: torch.Tensor, op=dist.ReduceOp.SUM, tag=None) -> torch.Tensor:
         if not t.is_contiguous():
             raise _lib.MtcError("mtc_comm: tensors must be contiguous")
+        e = self._timed(tag, t.numel() * t.element_size())
         check(self.lib.mtc_comm_all_reduce(self._h, _p(t), _p(t), t.numel(), self._code(t), self._OP[op], _stream()),
               "mtc_comm_all_reduce")
+        if e is not None:
+            e.record()
         return t
 
-    def reduce_scatter(self, t: torch.Tensor) -> torch.Tensor:
-        n = t.shape[0] // self.world
-        t = t.contiguous()
-        out = torch.empty((n,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    def reduce_scatter_into(self, out: torch.Tensor, t: torch.Tensor, tag=None) -> torch.Tensor:
+        e = self._timed(tag, t.numel() * t.element_size())
         check(self.lib.mtc_comm_reduce_scatter(self._h, _p(t), _p(out), out.numel(), self._code(t), 0, _stream()),
               "mtc_comm_reduce_scatter")
+        if e is not None:
+            e.record()
         return out
 
-    def reduce_scatter_begin(self, t: torch.Tensor):
-        return (None, self.reduce_scatter(t), None)          # in stream order (no second stream here)
+    def all_gather_into(self, out: torch.Tensor, t: torch.Tensor, tag=None) -> torch.Tensor:
+        e = self._timed(tag, out.numel() * out.element_size())
+        check(self.lib.mtc_comm_all_gather(self._h, _p(t), _p(out), t.numel(), self._code(t), _stream()), "mtc_comm_all_gather")
+        if e is not None:
+            e.record()
+        return out
 
-    @staticmethod
-    def reduce_scatter_end(handle) -> torch.Tensor:
-        return handle[1]
+    def reduce_scatter(self, t: torch.Tensor, tag=None) -> torch.Tensor:
+        n = t.shape[0] // self.world
+        out = torch.empty((n,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        return self.reduce_scatter_into(out, t.contiguous(), tag)
 
-    def all_gather_begin(self, t: torch.Tensor):
-        return (None, self.all_gather(t), None)              # in stream order (no second stream here)
-
-    all_gather_end = reduce_scatter_end
-
-    def all_gather(self, t: torch.Tensor) -> torch.Tensor:
+    def all_gather(self, t: torch.Tensor, tag=None) -> torch.Tensor:
         t = t.contiguous()
         out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-        check(self.lib.mtc_comm_all_gather(self._h, _p(t), _p(out), t.numel(), self._code(t), _stream()), "mtc_comm_all_gather")
-        return out
+        return self.all_gather_into(out, t, tag)
 
 
 class ShardedMatryoshkaTranscoder(MatryoshkaTranscoder):
-    _overlap_ok = False        # one stream: the step is a chain of kernels and collectives
+    _overlap_ok = False        # the step has its own second stream (the transport's), see _decode_and_losses
 
     def __init__(self, cfg: dict, group=None):
         if not dist.is_initialized():
@@ -250,6 +272,8 @@ class ShardedMatryoshkaTranscoder(MatryoshkaTranscoder):
         self.to(cfg["device"])
         self._cnt = self._cnt.to(cfg["device"])
         self.comm = _LibComm(group) if cfg.get("comm") == "libmtc" else _Comm(group)
+        self._sel_bufs = {}              # B -> exchange buffers / workspace of the sharded select (reused every step)
+        self._keep = None                # tensors the transport's stream still reads (freed when the next step starts)
 
     def hot_path(self) -> HotPath:
         if self._hp is None or self._hp.dtype != self.dtype:
@@ -257,50 +281,70 @@ class ShardedMatryoshkaTranscoder(MatryoshkaTranscoder):
                                bool(self.config.get("input_unit_norm", False)))
         return self._hp
 
+    def exchange_blocks(self, B: int) -> int:
+        """Row blocks the critical exchange is pipelined over (reduce-scatter of block i beside the decode of block i+1;
+        cfg["exchange_blocks"], default 4 when there is someone to exchange with, 1 at world 1)."""
+        nb = int(self.config.get("exchange_blocks", 4 if self.comm.world > 1 else 1))
+        while nb > 1 and B % (nb * self.comm.world):
+            nb -= 1
+        return max(nb, 1)
+
     # ------------------------------------------------------------------ step 2: global select
+    def _select_buffers(self, hp, d):
+        key = (d.B, str(self.W_dec.device), self.dtype)
+        bufs = self._sel_bufs.get(key)
+        if bufs is None:
+            dev, lib = self.W_dec.device, hp.lib
+            i32 = dict(dtype=torch.int32, device=dev)
+            ws_bytes = lib.mtc_select_sharded_workspace_bytes(C.byref(d))
+            n_pack = d.B * d.G + 1
+            bufs = dict(ws=torch.empty(ws_bytes, dtype=torch.uint8, device=dev), ws_bytes=ws_bytes,
+                        xbuf=torch.zeros(lib.mtc_select_sharded_xbuf_words(), **i32),
+                        hist_full=torch.zeros(lib.mtc_select_sharded_full_bins(), **i32),
+                        pack=torch.zeros(n_pack, **i32), all_pack=torch.zeros(self.comm.world * n_pack, **i32),
+                        carry=torch.zeros(8, **i32))
+            self._sel_bufs[key] = bufs
+        return bufs
+
     def _select(self, hp, d, acts, training: bool) -> Selection:
+        """sae.py:176-188 over the sharded dictionary: mtc_select_sharded_* (include/mtc.h) with three fixed-shape
+        collectives; the carried bound of the single-GPU select is used here too (bf16), ties are granted in ascending
+        global flat index, so the selection equals the single-GPU one whatever the world size."""
         if not training:
             return hp.select_threshold(d, acts, self.threshold)
-        lib, s, dev = hp.lib, _stream(), acts.device
+        lib, s, dev, comm = hp.lib, _stream(), acts.device, self.comm
         B = d.B
         k_total = int(self.config["top_k"]) * B
+        bf = self._select_buffers(hp, d)
         st = torch.empty(16, dtype=torch.int32, device=dev)
-        check(lib.mtc_select_init(_p(st), k_total, s), "mtc_select_init")
-        row_gt = torch.empty(B, dtype=torch.int32, device=dev)
-        row_eq = torch.empty(B + 1, dtype=torch.int32, device=dev)      # [B] tie counts + this shard's smallest selected value
         bf16 = self.dtype == torch.bfloat16
-        for level in range(1 if bf16 else lib.mtc_select_levels(C.byref(d))):
-            hist = torch.zeros(4096, dtype=torch.int32, device=dev)
-            check(lib.mtc_select_hist(C.byref(d), _p(acts), level, _p(st), _p(hist), s), "mtc_select_hist")
-            self.comm.all_reduce(hist)
-            check(lib.mtc_select_scan(C.byref(d), level, _p(hist), _p(st), s), "mtc_select_scan")
+        ws, xbuf, hist_full, pack, all_pack = bf["ws"], bf["xbuf"], bf["hist_full"], bf["pack"], bf["all_pack"]
+        carry = bf["carry"] if bf16 else None
+        check(lib.mtc_select_sharded_begin(C.byref(d), _p(acts), k_total, _p(ws), bf["ws_bytes"], _p(carry), _p(st), _p(xbuf),
+                                           _p(hist_full) if bf16 else None, _p(pack), s), "mtc_select_sharded_begin")
         if bf16:
-            # 3 key bits left: one pass per row, then the 8 sub-bin totals are all-reduced (32 bytes)
-            row_above = torch.empty(B, dtype=torch.int32, device=dev)
-            row_sub = torch.empty(B, 8, dtype=torch.int32, device=dev)
-            check(lib.mtc_select_rowsub(C.byref(d), _p(acts), _p(st), _p(row_above), _p(row_sub), s), "mtc_select_rowsub")
-            gsub = row_sub.sum(0, dtype=torch.int32)
-            self.comm.all_reduce(gsub)
-            check(lib.mtc_select_finish_rows(C.byref(d), _p(st), _p(row_above), _p(row_sub), _p(gsub), _p(row_gt),
-                                             _p(row_eq), s), "mtc_select_finish_rows")
+            comm.all_reduce(xbuf[:4104], tag="select window (all-reduce)")
+            check(lib.mtc_select_sharded_window(C.byref(d), _p(acts), k_total, _p(carry), _p(st), _p(xbuf), _p(hist_full), s),
+                  "mtc_select_sharded_window")
+            comm.all_reduce(hist_full, tag="select fallback (all-reduce)")
         else:
-            check(lib.mtc_select_count(C.byref(d), _p(acts), _p(st), None, _p(row_gt), _p(row_eq), s), "mtc_select_count")
-        row_eq[B:].copy_(st[6:7])                                                # min_sel_bits rides with the tie counts
-        all_eq = self.comm.all_gather(row_eq).contiguous()                      # [world, B + 1]
+            for level in range(lib.mtc_select_levels(C.byref(d))):
+                hist = xbuf[level * 4096:(level + 1) * 4096]
+                check(lib.mtc_select_hist(C.byref(d), _p(acts), level, _p(st), _p(hist), s), "mtc_select_hist")
+                comm.all_reduce(hist, tag="select level (all-reduce)")
+                check(lib.mtc_select_scan(C.byref(d), level, _p(hist), _p(st), s), "mtc_select_scan")
+        check(lib.mtc_select_sharded_counts(C.byref(d), _p(acts), k_total, _p(ws), _p(carry), _p(st),
+                                            _p(hist_full) if bf16 else None, _p(pack), s), "mtc_select_sharded_counts")
+        comm.all_gather_into(all_pack, pack, tag="select ties (all-gather)")
         row_ptr = torch.empty(B + 1, dtype=torch.int32, device=dev)
-        tie_take = torch.empty(B, dtype=torch.int32, device=dev)
-        glob = torch.empty(2, dtype=torch.int64, device=dev)
-        check(lib.mtc_select_offsets_sharded(C.byref(d), _p(row_gt), _p(all_eq), B + 1, self.comm.world, self.comm.rank, _p(st),
-                                             _p(row_ptr), _p(tie_take), _p(glob), s), "mtc_select_offsets_sharded")
         cap = max(k_total, 1)                       # a single rank can hold at most all k*B entries
         col_idx = torch.empty(cap, dtype=torch.int32, device=dev)
         vals = torch.empty(cap, dtype=self.dtype, device=dev)
-        check(lib.mtc_select_fill(C.byref(d), _p(acts), _p(st), None, _p(row_ptr), _p(tie_take), _p(col_idx), _p(vals), s),
-              "mtc_select_fill")
-        sel = Selection(st, row_ptr, col_idx, vals)
-        # threshold EMA (a5): the global smallest selected value came with the tie-count gather
-        check(lib.mtc_threshold_ema_global(C.byref(d), _p(glob), _p(self.threshold), 0.01, s), "mtc_threshold_ema_global")
-        return sel
+        # threshold EMA (a5) from the global smallest selected value rides in the finish launch
+        check(lib.mtc_select_sharded_finish(C.byref(d), _p(acts), _p(ws), _p(carry), _p(st), _p(all_pack), comm.world, comm.rank,
+                                            _p(row_ptr), _p(col_idx), _p(vals), _p(self.threshold), 0.01, s),
+              "mtc_select_sharded_finish")
+        return Selection(st, row_ptr, col_idx, vals)
 
     # ------------------------------------------------------------------ step 3: decode + losses
     def _aux_prepare(self, hp, d, aux_active: bool, side=None) -> bool:
@@ -446,79 +490,128 @@ class ShardedMatryoshkaTranscoder(MatryoshkaTranscoder):
         return dict(sel=asel, g_aux=g_aux, d_vals=d_aux), aux_rows
 
     def _decode_and_losses(self, hp, d, sel, acts, W_dec, b_dec, x_target, mean, std, need_grad, aux_active):
-        cfg = self.config
-        lib, s, dev = hp.lib, _stream(), x_target.device
-        B, A_t, G, W, rank = d.B, hp.A_t, d.G, self.comm.world, self.comm.rank
+        """a6-a10 over the sharded dictionary.  The batch is walked in `nb` row blocks; per block: local bias-free partial
+        sums (mtc_decode_partial) -> reduce-scatter of the last prefix (fp32) over the block's rows -> this rank finishes
+        its rows (x_hat, g, SSE) -> all-gather of g straight into the block's rows of g.  The two collectives of block i
+        run on the transport's stream beside the decode of block i+1 on the main stream; the earlier prefixes (FVU metrics
+        only, sae.py:248-252: model dtype), x_hat and the per-row statistics follow in ONE reduce-scatter + ONE all-gather
+        on that stream, beside the backward kernels when the fused step defers them."""
+        cfg, comm = self.config, self.comm
+        lib, dev = hp.lib, x_target.device
+        B, A_t, G, W, rank = d.B, hp.A_t, d.G, comm.world, comm.rank
         if B % W:
             raise _lib.MtcError(f"the batch ({B} rows) must be a multiple of the world size ({W})")
-        rps = B // W
-        # local bias-free partial sums: last prefix fp32, earlier prefixes (FVU only) in the model dtype
-        p_last = torch.empty(B, A_t, dtype=torch.float32, device=dev)
-        p_pre = torch.empty(W, max(G - 1, 1), rps, A_t, dtype=self.dtype, device=dev)
-        abs_rows = torch.empty(B, dtype=torch.float32, device=dev)
-        check(lib.mtc_decode_partial(C.byref(d), _p(sel.row_ptr), _p(sel.col_idx), _p(sel.vals), _p(W_dec), rps,
-                                     _p(p_last), _p(p_pre), _p(abs_rows), s), "mtc_decode_partial")
-        # reduce-scatter by batch rows: every rank finishes 1/W of the rows.  Only the LAST prefix is on the critical path
-        # (x_hat, g -> backward); the earlier prefixes feed FVU metrics only (sae.py:248-252), so inside the fused step
-        # their exchange is issued after the all-gather of g and runs beside the shard-local backward kernels
-        my_last = self.comm.reduce_scatter(p_last)                         # [rps, A_t] fp32
-        dl = _lib.make_desc(rps, hp.A_s, hp.A_t, hp.D, hp.prefix, hp.code, hp.unit_norm)
-        lo, hi = rank * rps, (rank + 1) * rps
-        mean_l = mean[lo:hi] if mean is not None else None
-        std_l = std[lo:hi] if std is not None else None
-        # one byte buffer per rank = {x_hat, g of its rows | per-row statistics | nnz, sum|a| of its shard}: ONE all-gather
-        # hands every rank all of g (its features fire on any row), the full reconstruction and the loss inputs
-        # Inside the fused step with the aux branch off, nothing reads the reconstruction before the output dict is built:
-        # it is then gathered by a collective of its own that runs beside the backward kernels (half of the bytes leave
-        # the critical path, and x_hat arrives contiguous).
-        deferred = bool(getattr(self, "_defer_dvals", False))
-        split = deferred and not aux_active
-        es = x_target.element_size()
-        n_xg, n_st = (1 if split else 2) * rps * A_t * es, (G + 4) * rps * 4
-        pack = torch.empty(n_xg + n_st + 8, dtype=torch.uint8, device=dev)
-        both_l = pack[:n_xg].view(self.dtype).view(-1, rps, A_t)
-        x_hat_l = torch.empty(rps, A_t, dtype=self.dtype, device=dev) if split else both_l[0]
-        g_l = both_l[-1]
-        stats_l = pack[n_xg:n_xg + n_st].view(torch.float32).view(G + 4, rps)
-        nnz_abs_l = pack[n_xg + n_st:].view(torch.float32)
+        nb = self.exchange_blocks(B)
+        Bb = B // nb                       # rows of a block
+        rpb = Bb // W                      # rows of a block this rank finishes
+        dt, es = self.dtype, x_target.element_size()
+        main = torch.cuda.current_stream()
+        cs = comm.comm_stream(dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        p_last = torch.empty(B, A_t, **f32)                               # block i = rows [i Bb, (i+1) Bb), shard-major inside
+        p_pre = torch.empty(W, nb, max(G - 1, 1), rpb, A_t, dtype=dt, device=dev)
+        abs_rows = torch.empty(B, **f32)
+        my_last = torch.empty(nb, rpb, A_t, **f32)
+        g = torch.empty(B, A_t, dtype=dt, device=dev)
+        g_l = torch.empty(nb, rpb, A_t, dtype=dt, device=dev)
+        x_hat = torch.empty(B, A_t, dtype=dt, device=dev)
+        # tail record of this rank (one all-gather): x_hat of its rows | per-row statistics | {nnz, sum |a|} of its shard
+        n_x, n_st = nb * rpb * A_t * es, nb * (G + 4) * rpb * 4
+        tail = torch.empty(n_x + n_st + 8, dtype=torch.uint8, device=dev)
+        x_hat_l = tail[:n_x].view(dt).view(nb, rpb, A_t)
+        stats_l = tail[n_x:n_x + n_st].view(torch.float32).view(nb, G + 4, rpb)
+        nnz_abs_l = tail[n_x + n_st:].view(torch.float32)
+        all_tail = torch.empty(W, n_x + n_st + 8, dtype=torch.uint8, device=dev)
         stats_l.zero_()
-        check(lib.mtc_shard_nnz_abs(C.byref(d), _p(abs_rows), _p(sel.state), _p(nnz_abs_l), s), "mtc_shard_nnz_abs")
-        check(lib.mtc_decode_finish(C.byref(dl), B, _p(my_last), None, _p(b_dec), _p(x_target[lo:hi]), _p(mean_l), _p(std_l),
-                                    _p(x_hat_l), _p(g_l), _p(stats_l), None, s), "mtc_decode_finish")
-        allp = self.comm.all_gather(pack)                                   # [W, bytes]
-        both = allp[:, :n_xg].view(self.dtype).view(W, -1, rps, A_t)
-        g = both[:, -1].reshape(B, A_t).contiguous()
-        row_stats = allp[:, n_xg:n_xg + n_st].view(torch.float32).view(W, G + 4, rps).permute(1, 0, 2).reshape(G + 4, B).contiguous()
-        nnz_abs = allp[:, n_xg + n_st:].view(torch.float32).sum(0).contiguous()
+        db = _lib.make_desc(Bb, hp.A_s, hp.A_t, hp.D, hp.prefix, hp.code, hp.unit_norm)
+        dl = _lib.make_desc(rpb, hp.A_s, hp.A_t, hp.D, hp.prefix, hp.code, hp.unit_norm)
+        pre_stride = nb * max(G - 1, 1) * rpb * A_t
+        rp, ev = sel.row_ptr, torch.cuda.Event
+
+        def my_rows(t, i):                 # rows of block i this rank finishes
+            return None if t is None else t[i * Bb + rank * rpb: i * Bb + (rank + 1) * rpb]
+
+        def finish_block(i):
+            check(lib.mtc_decode_finish(C.byref(dl), B, _p(my_last[i]), None, _p(b_dec), _p(my_rows(x_target, i)),
+                                        _p(my_rows(mean, i)), _p(my_rows(std, i)), _p(x_hat_l[i]), _p(g_l[i]), _p(stats_l[i]),
+                                        None, _stream()), "mtc_decode_finish")
+
+        e_ag = []
+        e_prev_rs = None
+        for i in range(nb):
+            check(lib.mtc_decode_partial_strided(C.byref(db), _p(rp[i * Bb:]), _p(sel.col_idx), _p(sel.vals), _p(W_dec), rpb,
+                                                 pre_stride, _p(p_last[i * Bb:]), _p(p_pre[0, i]), _p(abs_rows[i * Bb:]),
+                                                 _stream()), "mtc_decode_partial")
+            e_dp = ev()
+            e_dp.record(main)
+            if i > 0:                      # finish block i-1 behind the decode of block i (its reduce-scatter ran beside it)
+                main.wait_event(e_prev_rs)
+                finish_block(i - 1)
+                e_f = ev()
+                e_f.record(main)
+            with torch.cuda.stream(cs):
+                cs.wait_event(e_dp)
+                comm.reduce_scatter_into(my_last[i], p_last[i * Bb:(i + 1) * Bb], tag="partial reconstruction (reduce-scatter, fp32)")
+                e_prev_rs = ev()
+                e_prev_rs.record(cs)
+                if i > 0:
+                    cs.wait_event(e_f)
+                    comm.all_gather_into(g[(i - 1) * Bb: i * Bb], g_l[i - 1], tag="g (all-gather)")
+                    e = ev()
+                    e.record(cs)
+                    e_ag.append(e)
+        main.wait_event(e_prev_rs)
+        finish_block(nb - 1)
+        check(lib.mtc_shard_nnz_abs(C.byref(d), _p(abs_rows), _p(sel.state), _p(nnz_abs_l), _stream()), "mtc_shard_nnz_abs")
+        e_f = ev()
+        e_f.record(main)
         l1_term = float(cfg["l1_coeff"]) / (B * self.total_dict_size)
-        xh_handle = None
-        if split:
-            xh_handle = self.comm.all_gather_begin(x_hat_l)                 # valid once finish_metrics() has joined it
-            x_hat = xh_handle[1].reshape(B, A_t)
-        else:
-            x_hat = both[:, 0].reshape(B, A_t).contiguous()
-        pre_handle = self.comm.reduce_scatter_begin(p_pre) if G > 1 else None
+        deferred = bool(getattr(self, "_defer_dvals", False))
+        # the tail's finish runs beside the optimizer kernels: it must see THIS step's b_dec (a few KB), not the updated one
+        b_dec_fwd = b_dec.clone() if deferred and G > 1 else b_dec
+        row_stats = torch.empty(G + 4, B, **f32)
+        nnz_abs = torch.empty(2, **f32)
+        with torch.cuda.stream(cs):
+            cs.wait_event(e_f)
+            comm.all_gather_into(g[(nb - 1) * Bb:], g_l[nb - 1], tag="g (all-gather)")
+            e = ev()
+            e.record(cs)
+            e_ag.append(e)
+            # ---- off the critical path: earlier prefixes, x_hat, statistics
+            if G > 1:
+                my_pre = torch.empty(nb, G - 1, rpb, A_t, dtype=dt, device=dev)
+                comm.reduce_scatter_into(my_pre, p_pre, tag="earlier prefixes (reduce-scatter, model dtype)")
+                for i in range(nb):
+                    check(lib.mtc_decode_finish(C.byref(dl), B, None, _p(my_pre[i]), _p(b_dec_fwd), _p(my_rows(x_target, i)),
+                                                _p(my_rows(mean, i)), _p(my_rows(std, i)), None, None, _p(stats_l[i]), None,
+                                                _stream()), "mtc_decode_finish")
+            else:
+                my_pre = None
+            comm.all_gather_into(all_tail, tail, tag="x_hat + statistics (all-gather)")
+            # [W][nb][rpb][A_t] -> row order [nb][W][rpb][A_t]; statistics [W][nb][G+4][rpb] -> [G+4][nb][W][rpb]
+            x_hat.view(nb, W, rpb, A_t).copy_(all_tail[:, :n_x].view(dt).view(W, nb, rpb, A_t).transpose(0, 1))
+            row_stats.view(G + 4, nb, W, rpb).copy_(
+                all_tail[:, n_x:n_x + n_st].view(torch.float32).view(W, nb, G + 4, rpb).permute(2, 1, 0, 3))
+            torch.sum(all_tail[:, n_x + n_st:].view(torch.float32), 0, out=nnz_abs)
+            e_tail = ev()
+            e_tail.record(cs)
+        for e in e_ag:
+            main.wait_event(e)             # g is complete: the shard-local backward can start
+        # operands the transport's stream reads stay referenced until the next forward (allocator safety across streams)
+        self._keep = (p_last, p_pre, abs_rows, my_last, g_l, tail, all_tail, my_pre, b_dec_fwd, x_target, mean, std)
         aux, aux_rows = None, None
         if aux_active:
+            main.wait_event(e_tail)        # the aux branch reads x_hat
+            e_tail = None
             aux, aux_rows = self._run_aux(hp, d, acts, sel, W_dec, x_target, x_hat, g, need_grad, l1_term)
         # the fused step derives d a_bj inside the decoder-gradient kernel, also with the dense aux branch active
-        defer = getattr(self, "_defer_dvals", False) and (aux is None or bool(aux.get("dense")))
+        defer = deferred and (aux is None or bool(aux.get("dense")))
         d_vals = hp.decode_bwd_vals(d, sel, W_dec, g, l1_term) if need_grad and not defer else None
-        scalars = torch.empty(16, dtype=torch.float32, device=dev)
-        # the deferred part runs after the optimizer kernels: it must see THIS step's b_dec (a few KB), not the updated one
-        b_dec_fwd = b_dec.clone() if deferred and pre_handle is not None else b_dec
+        scalars = torch.empty(16, **f32)
 
         def finish_metrics():
-            if xh_handle is not None:
-                self.comm.all_gather_end(xh_handle)                         # x_hat (the output dict's transcoder_out)
-            # SSE of prefixes 0 .. G-2 on this rank's rows, gathered into the per-row statistics; then the scalars
-            if pre_handle is not None:
-                my_pre = self.comm.reduce_scatter_end(pre_handle)[0]        # [G-1, rps, A_t]
-                sse_pre = torch.zeros(G + 4, rps, dtype=torch.float32, device=dev)
-                check(lib.mtc_decode_finish(C.byref(dl), B, None, _p(my_pre), _p(b_dec_fwd), _p(x_target[lo:hi]), _p(mean_l),
-                                            _p(std_l), None, None, _p(sse_pre), None, _stream()), "mtc_decode_finish")
-                allq = self.comm.all_gather(sse_pre[:G - 1].contiguous())   # [W, G-1, rps]
-                row_stats[:G - 1] = allq.permute(1, 0, 2).reshape(G - 1, B)
+            if e_tail is not None:
+                torch.cuda.current_stream().wait_event(e_tail)
             hp.reduce_scalars(d, row_stats, sel, self.total_dict_size, float(cfg["l1_coeff"]), float(cfg["aux_penalty"]),
                               aux_rows=aux_rows, nnz_abs_override=nnz_abs, out=scalars)
 

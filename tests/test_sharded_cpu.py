@@ -71,11 +71,39 @@ def test_layout_partition():
         ShardLayout([16, 48, 112, 256], 4, 0)          # groups must split into multiples of 8 per rank
 
 
-def test_tie_before_order():
-    from matryoshka_transcoder_amd.sharded import tie_before
-    all_eq = torch.tensor([[1, 0, 2], [3, 1, 0]])        # [world=2, B=3]
-    assert tie_before(all_eq, 0).tolist() == [0, 4, 5]
-    assert tie_before(all_eq, 1).tolist() == [1, 4, 7]
+def test_tie_grant_is_global_flat_index_order():
+    """Ties at tau are granted in ascending GLOBAL flat index (what the single-GPU select does), whatever the world
+    size: brute force over the global feature order against the per-(row, group) arithmetic the kernel uses."""
+    from matryoshka_transcoder_amd.sharded import ShardLayout, tie_take_global_order
+    g = torch.Generator().manual_seed(5)
+    prefix = [32, 96, 224, 512]
+    B = 6
+    tie_mask = torch.rand(B, prefix[-1], generator=g) < 0.08           # global [B, D]: entries equal to tau
+    total = int(tie_mask.sum())
+    for world in (1, 2, 4):
+        lay0 = ShardLayout(prefix, world, 0)
+        bounds = [0] + lay0.local_prefix
+        all_eq = torch.zeros(world, B, len(prefix), dtype=torch.int64)
+        local_masks = []
+        for r in range(world):
+            lm = tie_mask[:, lay0.global_index(r)]                     # this rank's columns, local order
+            local_masks.append(lm)
+            for gi in range(len(prefix)):
+                all_eq[r, :, gi] = lm[:, bounds[gi]:bounds[gi + 1]].sum(1)
+        for quota in (0, 1, total // 3, total - 1, total, total + 5):
+            # brute force: the first `quota` ties in (row, global feature) order
+            flat_pos = tie_mask.reshape(-1).nonzero().reshape(-1)[:quota]
+            granted = torch.zeros(B * prefix[-1], dtype=torch.bool)
+            granted[flat_pos] = True
+            granted = granted.reshape(B, prefix[-1])
+            for r in range(world):
+                want_mask = granted[:, lay0.global_index(r)]
+                take = tie_take_global_order(all_eq, quota, r)
+                assert take.tolist() == want_mask.sum(1).tolist(), (world, quota, r)
+                # and it is a PREFIX of the row's local ties (one number per row describes it)
+                for b in range(B):
+                    loc = local_masks[r][b].nonzero().reshape(-1)[: int(take[b])]
+                    assert torch.equal(want_mask[b].nonzero().reshape(-1), loc), (world, quota, r, b)
 
 
 def _state_dict_roundtrip(rank, world):
