@@ -120,6 +120,23 @@ def stage_times(tc, opt, pool, reps=5):
               "backward", "fused_backward_adam", "colsum", "unitnorm_adam", "adam_flat", "aux_dead_list", "aux_forward_dense",
               "aux_extra_rows"):
         wrap(n)
+    # the feature-sharded classes sequence their select / decode + exchanges themselves (sharded.py): timed as a whole,
+    # on the main stream (waits for the transport's stream included)
+    model_wrapped = {}
+    if hasattr(tc, "comm"):
+        for n, label in (("_select", "select (sharded: 4 phases + 3 collectives)"),
+                         ("_decode_and_losses", "decode + exchanges (sharded)")):
+            fn = getattr(tc, n)
+            model_wrapped[n] = fn
+
+            def inner(*a, _fn=fn, _label=label, **k):
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                r = _fn(*a, **k)
+                e1.record()
+                names.append(_label); evs.append((e0, e1))
+                return r
+            object.__setattr__(tc, n, inner)
     acc = {}
     for r in range(reps):
         names.clear(); evs.clear()
@@ -130,6 +147,8 @@ def stage_times(tc, opt, pool, reps=5):
             acc.setdefault(n, []).append(e0.elapsed_time(e1))
     for n, fn in orig.items():
         setattr(hp, n, fn)
+    for n in model_wrapped:
+        object.__delattr__(tc, n)
     tc._overlap_ok, tc._side_stream = overlap_was, side_was
     out = {}
     # several calls of one stage inside a step (adam_flat x3) are summed per step
@@ -177,6 +196,8 @@ def main():
     ap.add_argument("--sharded", action="store_true", help="use the feature-sharded classes even on one GPU (overhead check)")
     ap.add_argument("--comm", default="torch", choices=["torch", "libmtc"],
                     help="transport of the sharded step's exchanges: torch.distributed (RCCL) or libmtc's own RCCL wrappers")
+    ap.add_argument("--exchange-blocks", type=int, default=0,
+                    help="row blocks the sharded step pipelines its critical exchange over (0 = default: 4 at world > 1, 1 at world 1)")
     ap.add_argument("--aux-active", action="store_true",
                     help="SURVEY 8d: the step with the auxiliary dead-feature loss active (every 7th feature forced dead: "
                          "tiny encoder column, counter preset); adds an `aux` block (its GEMMs on mtc_gemm_nt) to the line")
@@ -233,6 +254,8 @@ def main():
         from matryoshka_transcoder_amd.sharded import ShardedMatryoshkaTranscoder, ShardedFusedAdam
         if args.comm == "libmtc" and collective_backend == "nccl":
             cfg["comm"] = "libmtc"
+        if args.exchange_blocks > 0:
+            cfg["exchange_blocks"] = args.exchange_blocks
         tc = ShardedMatryoshkaTranscoder(cfg)
         opt = ShardedFusedAdam(tc, lr=cfg["lr"], betas=(cfg["beta1"], cfg["beta2"]))
     else:
@@ -319,6 +342,26 @@ def main():
                    "collective_backend": collective_backend,
                    "final_loss": float(out["loss"].detach().float()), "final_l0": float(out["l0_norm"].detach())},
     }
+    if world > 1 or args.sharded:
+        # After the timed region, on EVERY rank (collectives): a few instrumented steps -- HIP events around each exchange
+        # on the stream it runs on, and around the stages of the sharded step on the main stream -- so that a scaling
+        # curve can be read from its own lines.  RCCL knobs are passed through the environment and recorded.
+        n_diag = 5
+        tc.comm.timing = {}
+        st = stage_times(tc, opt, pool, reps=n_diag)
+        fence()
+        timing, tc.comm.timing = tc.comm.timing, None
+        exchanges = {}
+        for tag, lst in timing.items():
+            ms = [a.elapsed_time(b) for a, b, _ in lst]
+            nbytes = lst[0][2]
+            exchanges[tag] = {"calls_per_step": len(lst) / n_diag, "ms_per_call": sum(ms) / len(ms), "payload_bytes_per_call": nbytes,
+                              "GBps": nbytes / (sum(ms) / len(ms) * 1e-3) / 1e9 if sum(ms) > 0 else None}
+        result["stages"] = {n: {"ms": t} for n, t in st.items()}
+        result["exchanges"] = exchanges
+        result["config"]["exchange_blocks"] = tc.exchange_blocks(B)
+        result["config"]["transport"] = type(tc.comm).__name__
+        result["config"]["rccl_env"] = {k2: v for k2, v in os.environ.items() if k2.startswith(("NCCL_", "RCCL_"))}
     if rank == 0 and world == 1 and not args.sharded:
         if args.aux_active:
             force_dead()          # the timed steps revived most of the dead set: per-stage times are taken on a full one again

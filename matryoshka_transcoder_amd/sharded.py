@@ -538,10 +538,14 @@ class ShardedMatryoshkaTranscoder(MatryoshkaTranscoder):
 
         e_ag = []
         e_prev_rs = None
+        one_block = nb == 1                # nothing to overlap on the critical path: its two exchanges stay on the main stream
         for i in range(nb):
             check(lib.mtc_decode_partial_strided(C.byref(db), _p(rp[i * Bb:]), _p(sel.col_idx), _p(sel.vals), _p(W_dec), rpb,
                                                  pre_stride, _p(p_last[i * Bb:]), _p(p_pre[0, i]), _p(abs_rows[i * Bb:]),
                                                  _stream()), "mtc_decode_partial")
+            if one_block:
+                comm.reduce_scatter_into(my_last[0], p_last, tag="partial reconstruction (reduce-scatter, fp32)")
+                break
             e_dp = ev()
             e_dp.record(main)
             if i > 0:                      # finish block i-1 behind the decode of block i (its reduce-scatter ran beside it)
@@ -560,9 +564,12 @@ class ShardedMatryoshkaTranscoder(MatryoshkaTranscoder):
                     e = ev()
                     e.record(cs)
                     e_ag.append(e)
-        main.wait_event(e_prev_rs)
+        if not one_block:
+            main.wait_event(e_prev_rs)
         finish_block(nb - 1)
         check(lib.mtc_shard_nnz_abs(C.byref(d), _p(abs_rows), _p(sel.state), _p(nnz_abs_l), _stream()), "mtc_shard_nnz_abs")
+        if one_block:
+            comm.all_gather_into(g, g_l[0], tag="g (all-gather)")
         e_f = ev()
         e_f.record(main)
         l1_term = float(cfg["l1_coeff"]) / (B * self.total_dict_size)
@@ -573,10 +580,11 @@ class ShardedMatryoshkaTranscoder(MatryoshkaTranscoder):
         nnz_abs = torch.empty(2, **f32)
         with torch.cuda.stream(cs):
             cs.wait_event(e_f)
-            comm.all_gather_into(g[(nb - 1) * Bb:], g_l[nb - 1], tag="g (all-gather)")
-            e = ev()
-            e.record(cs)
-            e_ag.append(e)
+            if not one_block:
+                comm.all_gather_into(g[(nb - 1) * Bb:], g_l[nb - 1], tag="g (all-gather)")
+                e = ev()
+                e.record(cs)
+                e_ag.append(e)
             # ---- off the critical path: earlier prefixes, x_hat, statistics
             if G > 1:
                 my_pre = torch.empty(nb, G - 1, rpb, A_t, dtype=dt, device=dev)

@@ -39,16 +39,16 @@ def main():
         else:
             tc = MatryoshkaTranscoder(cfg)
             opt = FusedAdam(tc, lr=3e-4, betas=(0.9, 0.99))
-        pool = bench.batch_pool(B, cfg["act_size"], torch.bfloat16, "cuda:0", n=2)
+        pool = bench.batch_pool(B, cfg["act_size"], torch.bfloat16, "cuda:0", n=8)
         for i in range(5):
-            opt.train_step(*pool[i % 2])
+            opt.train_step(*pool[i % 8])
         torch.cuda.synchronize()
         prof = cProfile.Profile() if args.profile == f"{wl}:{int(sharded)}" else None
         t0 = time.perf_counter()
         if prof:
             prof.enable()
         for i in range(50):
-            opt.train_step(*pool[i % 2])
+            opt.train_step(*pool[i % 8])
         if prof:
             prof.disable()
         t_host = (time.perf_counter() - t0) / 50
