@@ -196,6 +196,8 @@ def main():
     ap.add_argument("--sharded", action="store_true", help="use the feature-sharded classes even on one GPU (overhead check)")
     ap.add_argument("--comm", default="torch", choices=["torch", "libmtc"],
                     help="transport of the sharded step's exchanges: torch.distributed (RCCL) or libmtc's own RCCL wrappers")
+    ap.add_argument("--world1-exchanges", action="store_true",
+                    help="--sharded at world 1: call the transport for the (identity) exchanges too instead of aliasing the buffers")
     ap.add_argument("--exchange-blocks", type=int, default=0,
                     help="row blocks the sharded step pipelines its critical exchange over (0 = default: 4 at world > 1, 1 at world 1)")
     ap.add_argument("--aux-active", action="store_true",
@@ -256,6 +258,7 @@ def main():
             cfg["comm"] = "libmtc"
         if args.exchange_blocks > 0:
             cfg["exchange_blocks"] = args.exchange_blocks
+        cfg["world1_exchanges"] = bool(args.world1_exchanges)
         tc = ShardedMatryoshkaTranscoder(cfg)
         opt = ShardedFusedAdam(tc, lr=cfg["lr"], betas=(cfg["beta1"], cfg["beta2"]))
     else:
@@ -337,7 +340,7 @@ def main():
         "config": {"workload": f"{args.workload}: act {A}, dict {D}, cumulative prefixes {cfg['prefix_sizes']}, "
                                f"top_k {k}, batch {B}, input_unit_norm {args.unit_norm}"
                                + (f", auxiliary loss ACTIVE ({n_forced} features forced dead)" if args.aux_active else ""),
-                   "global_batch": B, "parallelism": "single GPU" if world == 1 else f"dictionary sharded x{world}",
+                   "global_batch": B, "parallelism": f"dictionary sharded x{world}" if (world > 1 or args.sharded) else "single GPU",
                    "collective_world": world if (world > 1 or args.sharded) else None,
                    "collective_backend": collective_backend,
                    "final_loss": float(out["loss"].detach().float()), "final_l0": float(out["l0_norm"].detach())},

@@ -282,9 +282,11 @@ class ShardedMatryoshkaTranscoder(MatryoshkaTranscoder):
         return self._hp
 
     def exchange_blocks(self, B: int) -> int:
-        """Row blocks the critical exchange is pipelined over (reduce-scatter of block i beside the decode of block i+1;
-        cfg["exchange_blocks"], default 4 when there is someone to exchange with, 1 at world 1)."""
-        nb = int(self.config.get("exchange_blocks", 4 if self.comm.world > 1 else 1))
+        """Row blocks the critical exchange is pipelined over (reduce-scatter of block i beside the decode of block i+1).
+        cfg["exchange_blocks"]; default: blocks of >= 4096 rows, at most 4, when there is someone to exchange with -- a
+        decode launch over fewer rows leaves CUs idle (1024-row blocks at config #2 measured +0.24 ms per step at world 1),
+        so only the large batches (Gemma-2-9B / 27B shapes: 8192 / 16384 rows) are cut by default."""
+        nb = int(self.config.get("exchange_blocks", min(4, max(B // 4096, 1)) if self.comm.world > 1 else 1))
         while nb > 1 and B % (nb * self.comm.world):
             nb -= 1
         return max(nb, 1)
@@ -511,9 +513,13 @@ class ShardedMatryoshkaTranscoder(MatryoshkaTranscoder):
         p_last = torch.empty(B, A_t, **f32)                               # block i = rows [i Bb, (i+1) Bb), shard-major inside
         p_pre = torch.empty(W, nb, max(G - 1, 1), rpb, A_t, dtype=dt, device=dev)
         abs_rows = torch.empty(B, **f32)
-        my_last = torch.empty(nb, rpb, A_t, **f32)
+        # world 1: every exchange is an identity (RCCL would copy each buffer onto a second one, 130 MB per step at config
+        # #2 for nothing): the "received" buffers alias the "sent" ones and the calls are skipped, unless
+        # cfg["world1_exchanges"] asks for them (tests: the transport's calls at the real shapes)
+        ident = W == 1 and not cfg.get("world1_exchanges", False)
         g = torch.empty(B, A_t, dtype=dt, device=dev)
-        g_l = torch.empty(nb, rpb, A_t, dtype=dt, device=dev)
+        my_last = p_last.view(nb, rpb, A_t) if ident else torch.empty(nb, rpb, A_t, **f32)
+        g_l = g.view(nb, rpb, A_t) if ident else torch.empty(nb, rpb, A_t, dtype=dt, device=dev)
         x_hat = torch.empty(B, A_t, dtype=dt, device=dev)
         # tail record of this rank (one all-gather): x_hat of its rows | per-row statistics | {nnz, sum |a|} of its shard
         n_x, n_st = nb * rpb * A_t * es, nb * (G + 4) * rpb * 4
@@ -521,7 +527,7 @@ class ShardedMatryoshkaTranscoder(MatryoshkaTranscoder):
         x_hat_l = tail[:n_x].view(dt).view(nb, rpb, A_t)
         stats_l = tail[n_x:n_x + n_st].view(torch.float32).view(nb, G + 4, rpb)
         nnz_abs_l = tail[n_x + n_st:].view(torch.float32)
-        all_tail = torch.empty(W, n_x + n_st + 8, dtype=torch.uint8, device=dev)
+        all_tail = tail.view(1, -1) if ident else torch.empty(W, n_x + n_st + 8, dtype=torch.uint8, device=dev)
         stats_l.zero_()
         db = _lib.make_desc(Bb, hp.A_s, hp.A_t, hp.D, hp.prefix, hp.code, hp.unit_norm)
         dl = _lib.make_desc(rpb, hp.A_s, hp.A_t, hp.D, hp.prefix, hp.code, hp.unit_norm)
@@ -544,7 +550,8 @@ class ShardedMatryoshkaTranscoder(MatryoshkaTranscoder):
                                                  pre_stride, _p(p_last[i * Bb:]), _p(p_pre[0, i]), _p(abs_rows[i * Bb:]),
                                                  _stream()), "mtc_decode_partial")
             if one_block:
-                comm.reduce_scatter_into(my_last[0], p_last, tag="partial reconstruction (reduce-scatter, fp32)")
+                if not ident:
+                    comm.reduce_scatter_into(my_last[0], p_last, tag="partial reconstruction (reduce-scatter, fp32)")
                 break
             e_dp = ev()
             e_dp.record(main)
@@ -555,12 +562,14 @@ class ShardedMatryoshkaTranscoder(MatryoshkaTranscoder):
                 e_f.record(main)
             with torch.cuda.stream(cs):
                 cs.wait_event(e_dp)
-                comm.reduce_scatter_into(my_last[i], p_last[i * Bb:(i + 1) * Bb], tag="partial reconstruction (reduce-scatter, fp32)")
+                if not ident:
+                    comm.reduce_scatter_into(my_last[i], p_last[i * Bb:(i + 1) * Bb], tag="partial reconstruction (reduce-scatter, fp32)")
                 e_prev_rs = ev()
                 e_prev_rs.record(cs)
                 if i > 0:
                     cs.wait_event(e_f)
-                    comm.all_gather_into(g[(i - 1) * Bb: i * Bb], g_l[i - 1], tag="g (all-gather)")
+                    if not ident:
+                        comm.all_gather_into(g[(i - 1) * Bb: i * Bb], g_l[i - 1], tag="g (all-gather)")
                     e = ev()
                     e.record(cs)
                     e_ag.append(e)
@@ -568,7 +577,7 @@ class ShardedMatryoshkaTranscoder(MatryoshkaTranscoder):
             main.wait_event(e_prev_rs)
         finish_block(nb - 1)
         check(lib.mtc_shard_nnz_abs(C.byref(d), _p(abs_rows), _p(sel.state), _p(nnz_abs_l), _stream()), "mtc_shard_nnz_abs")
-        if one_block:
+        if one_block and not ident:
             comm.all_gather_into(g, g_l[0], tag="g (all-gather)")
         e_f = ev()
         e_f.record(main)
@@ -581,21 +590,26 @@ class ShardedMatryoshkaTranscoder(MatryoshkaTranscoder):
         with torch.cuda.stream(cs):
             cs.wait_event(e_f)
             if not one_block:
-                comm.all_gather_into(g[(nb - 1) * Bb:], g_l[nb - 1], tag="g (all-gather)")
+                if not ident:
+                    comm.all_gather_into(g[(nb - 1) * Bb:], g_l[nb - 1], tag="g (all-gather)")
                 e = ev()
                 e.record(cs)
                 e_ag.append(e)
             # ---- off the critical path: earlier prefixes, x_hat, statistics
             if G > 1:
-                my_pre = torch.empty(nb, G - 1, rpb, A_t, dtype=dt, device=dev)
-                comm.reduce_scatter_into(my_pre, p_pre, tag="earlier prefixes (reduce-scatter, model dtype)")
+                if ident:
+                    my_pre = p_pre.view(nb, G - 1, rpb, A_t)
+                else:
+                    my_pre = torch.empty(nb, G - 1, rpb, A_t, dtype=dt, device=dev)
+                    comm.reduce_scatter_into(my_pre, p_pre, tag="earlier prefixes (reduce-scatter, model dtype)")
                 for i in range(nb):
                     check(lib.mtc_decode_finish(C.byref(dl), B, None, _p(my_pre[i]), _p(b_dec_fwd), _p(my_rows(x_target, i)),
                                                 _p(my_rows(mean, i)), _p(my_rows(std, i)), None, None, _p(stats_l[i]), None,
                                                 _stream()), "mtc_decode_finish")
             else:
                 my_pre = None
-            comm.all_gather_into(all_tail, tail, tag="x_hat + statistics (all-gather)")
+            if not ident:
+                comm.all_gather_into(all_tail, tail, tag="x_hat + statistics (all-gather)")
             # [W][nb][rpb][A_t] -> row order [nb][W][rpb][A_t]; statistics [W][nb][G+4][rpb] -> [G+4][nb][W][rpb]
             x_hat.view(nb, W, rpb, A_t).copy_(all_tail[:, :n_x].view(dt).view(W, nb, rpb, A_t).transpose(0, 1))
             row_stats.view(G + 4, nb, W, rpb).copy_(

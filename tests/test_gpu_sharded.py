@@ -84,6 +84,7 @@ def _worker(rank, world, port, dt_name, unit, fused, aux, ret, backend="gloo", c
         cfg = _cfg(dt, unit, aux)
         if comm:
             cfg["comm"] = comm
+        cfg["world1_exchanges"] = True      # a one-rank group still calls the transport (identity exchanges over RCCL)
         m = ShardedMatryoshkaTranscoder(cfg)
         opt = ShardedFusedAdam(m, lr=cfg["lr"], betas=(cfg["beta1"], cfg["beta2"]))
         first = []
@@ -222,7 +223,8 @@ def _cfg2(dt, blocks):
     # BASELINE.json configs 2 / 3: Gemma-2-2B shapes (A 2304, D 36864, k 96, B 4096), dictionary sharded
     return dict(seed=49, prefix_sizes=[2304, 6912, 16128, 36864], act_size=2304, top_k=96, top_k_aux=512,
                 aux_penalty=1 / 32, n_batches_to_dead=20, l1_coeff=0.0, dtype=dt, device="cuda:0",
-                input_unit_norm=False, lr=3e-4, beta1=0.9, beta2=0.99, exchange_blocks=blocks)
+                input_unit_norm=False, lr=3e-4, beta1=0.9, beta2=0.99, exchange_blocks=blocks,
+                world1_exchanges=True)       # a one-rank group still calls the transport (identity exchanges over RCCL)
 
 
 def _batches2(dt, n=3, B=4096, A=2304):
