@@ -118,6 +118,21 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
+// the same with a cache-policy operand (2 = non-temporal): experiments on the persistent kernel's operand streams
+template <int AUX>
+__device__ __forceinline__ void glds16_aux(const void* gsrc, void* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, AUX);
+}
+#ifndef MTC_ENC_GROUP
+#define MTC_ENC_GROUP 4
+#endif
+#ifndef MTC_ENC_W_AUX
+#define MTC_ENC_W_AUX 0
+#endif
+#ifndef MTC_ENC_X_AUX
+#define MTC_ENC_X_AUX 0
+#endif
 
 // EPI 0: the encoder (round, + bias, round, ReLU / threshold; lda = ldb = K, ldc = N).  EPI 1 / 2: plain C = A . Bt^T
 // (mtc_gemm_nt: the auxiliary branch's products) rounded once to bf16 / kept in fp32, with row strides lda / ldb / ldc
@@ -573,7 +588,7 @@ __device__ __forceinline__ uint32_t bias_relu_pack2(float v0, float v1, float b0
 }
 
 __device__ __forceinline__ void lid_to_tile(int lid, int mt, int nt, int& tm, int& tn) {
-    constexpr int GROUP = 4;     // logical ids walk GROUP-wide groups of batch tiles under each feature tile (see xcd_tile_coords)
+    constexpr int GROUP = MTC_ENC_GROUP;     // logical ids walk GROUP-wide groups of batch tiles under each feature tile (see xcd_tile_coords)
     const int per_group = GROUP * nt;
     const int g = lid / per_group;
     const int first_m = g * GROUP;
@@ -656,13 +671,13 @@ __global__ __launch_bounds__(512, 1) void encode_bf16_mfma256p_kernel(const u16*
     };
     auto stage_w = [&](int buf, int h, int kt) {
         char* base = smem + buf * 4 * HALF_BYTES + h * HALF_BYTES + wid * 2 * 1024;
-        glds16(wsrc[h][0] + kt * BK, base);
-        glds16(wsrc[h][1] + kt * BK, base + 1024);
+        glds16_aux<MTC_ENC_W_AUX>(wsrc[h][0] + kt * BK, base);
+        glds16_aux<MTC_ENC_W_AUX>(wsrc[h][1] + kt * BK, base + 1024);
     };
     auto stage_x = [&](int buf, int h, int kt) {
         char* base = smem + buf * 4 * HALF_BYTES + (2 + h) * HALF_BYTES + wid * 2 * 1024;
-        glds16(xsrc[h][0] + kt * BK, base);
-        glds16(xsrc[h][1] + kt * BK, base + 1024);
+        glds16_aux<MTC_ENC_X_AUX>(xsrc[h][0] + kt * BK, base);
+        glds16_aux<MTC_ENC_X_AUX>(xsrc[h][1] + kt * BK, base + 1024);
     };
     // the two operand streams run ahead of the MFMAs by one (W) / two (X) k-steps and cross tile boundaries
     int wk = 0, wm = 0, xk = 0, xm = 0;                                           // next stage to issue: k-tile, tile ordinal
