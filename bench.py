@@ -91,6 +91,31 @@ def cpu_baseline(workload, dtype, budget_rows=None, steps=3):
                       f"oracle.DenseStep (dense eager port of the reference step)"}
 
 
+def hbm_calibration(device, gib=1.0, reps=10):
+    """Streaming-copy rate of this GPU in this process: libmtc's own 16-byte-per-lane copy kernel (mtc_copy16) over a
+    buffer far larger than the Infinity Cache, read + write bytes per second.  SURVEY 8d: the HBM-bound stages are shown
+    against the 8 TB/s peak AND against this."""
+    import ctypes as C
+    from matryoshka_transcoder_amd import _lib
+    lib = _lib.load()
+    n = int(gib * (1 << 30))
+    src = torch.empty(n, dtype=torch.uint8, device=device)
+    dst = torch.empty(n, dtype=torch.uint8, device=device)
+    src.zero_()
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for _ in range(2):
+        _lib.check(lib.mtc_copy16(C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()), n, s), "mtc_copy16")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        _lib.check(lib.mtc_copy16(C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()), n, s), "mtc_copy16")
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    return {"kernel": "mtc::copy16_kernel (16 B per lane, non-temporal)", "bytes_copied": n, "ms": ms,
+            "GBps_read_plus_write": 2.0 * n / (ms * 1e-3) / 1e9}
+
+
 def stage_times(tc, opt, pool, reps=5):
     """Per-stage device time of one step, HIP events on the launch stream (torch's current stream).  Stages are timed
     one after the other on ONE stream: the side-stream overlap of the production step (CSC build under the decode,
@@ -375,13 +400,18 @@ def main():
         # algorithmic work per launch: "hbm" = bytes that must cross HBM at least
         # once (weights / moments / activations streamed, outputs written); "gather" = bytes the k-sparse row
         # gathers request on top of that, served by L2 / Infinity Cache (reported, not priced against HBM)
+        # Two prices per HBM-bound stage.  "compulsory": bytes that must cross HBM at least once whatever the
+        # implementation (tables streamed once, outputs written).  "algorithmic" (SURVEY 8d): the k-sparse row gathers
+        # counted per selected entry -- nnz rows of A elements per sweep -- plus the streams; the gathers are served by
+        # L2 / Infinity Cache where the table fits, so this rate can exceed what HBM alone delivers.
         algo = {
             "encode": ("mfma", flop_enc, 0),
             "select_topk": ("hbm", B * D * s + nnz * (4 + s) + B * 4, 0),
-            "decode": ("hbm", D * A * s + nnz * (4 + s) + 3 * B * A * s, nnz * A * s),      # one sweep: d_vals is deferred
-            "fused_backward_adam": ("hbm", 2 * D * A * 6 * s + 2 * B * A * s + nnz * 20, 2 * nnz * A * s),
-            "backward": ("hbm", 2 * D * A * s + 2 * B * A * s + nnz * 12, 2 * nnz * A * s),
+            "decode": ("hbm", D * A * s + nnz * (4 + s) + 3 * B * A * s, nnz * A * s - D * A * s),      # one sweep: d_vals is deferred
+            "fused_backward_adam": ("hbm", 2 * D * A * 6 * s + 2 * B * A * s + nnz * 20, 2 * nnz * A * s - 2 * B * A * s),
+            "backward": ("hbm", 2 * D * A * s + 2 * B * A * s + nnz * 12, 2 * nnz * A * s - 2 * B * A * s),
         }
+        calib = hbm_calibration(device)
         # stage -> (launches per step, kernel name in the committed PMC summary) for the stages priced below
         launches = {"encode": (1, "mtc::encode_bf16_mfma256p_kernel<false>"), "decode": (1, "mtc::decode_fwd_kernel<1, 5>"),
                     "fused_backward_adam": (2, "mtc::fused_grad_adam_kernel<1, 1, 5, 1, 1, 0>")}     # (+ fused_enc_sliced_kernel)
@@ -390,15 +420,17 @@ def main():
             entry = {"ms": t_ms, "launches": launches.get(n, (None, None))[0]}
             if n in algo:
                 kind, q, gather = algo[n]
-                if gather:
-                    entry["gather_GBps"] = gather / (t_ms * 1e-3) / 1e9
                 if kind == "mfma":
                     peak = MFMA_BF16_PEAK_TF if dtype == torch.bfloat16 else MFMA_F32_PEAK_TF
                     ach = q / (t_ms * 1e-3) / 1e12
                     entry.update(bound="mfma", achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak)
                 else:
                     ach = q / (t_ms * 1e-3) / 1e9
-                    entry.update(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS)
+                    alg = (q + max(gather, 0)) / (t_ms * 1e-3) / 1e9
+                    entry.update(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
+                                 compulsory_bytes=int(q), algorithmic_bytes=int(q + max(gather, 0)),
+                                 frac_compulsory=ach / HBM_PEAK_GBS, algorithmic_GBps=alg, frac_algorithmic=alg / HBM_PEAK_GBS,
+                                 frac_algorithmic_of_copy_rate=alg / calib["GBps_read_plus_write"])
             kernels[n] = entry
         # dominant KERNEL = longest single launch (the fused stage is two launches of one kernel template)
         per_launch = lambda n: kernels[n]["ms"] / (kernels[n]["launches"] or 1)
@@ -413,7 +445,7 @@ def main():
         # profiles/README.md); only valid for the workload / dtype they were taken on
         traffic = None
         import glob
-        pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r02*_pmc_traffic.json")))      # newest round-2 summary
+        pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[23]*_pmc_traffic.json")))    # newest committed summary
         traffic_src = None
         if args.workload == "gemma2-2b" and args.dtype == "bf16" and not args.unit_norm and pmc_files:
             with open(pmc_files[-1]) as f:
@@ -425,6 +457,7 @@ def main():
                               "launch_ms": per_launch(dom), "traffic": traffic, "traffic_unit": "bytes/launch",
                               "traffic_source": traffic_src}
         result["stages"] = kernels
+        result["hbm_calibration"] = calib
         if args.aux_active:
             # the branch's four products over the dead set (sae.py:336-341 and its autograd), all on mtc_gemm_nt:
             # forward B x A_t x n_pad, backward 3 products of the same volume; priced against the dense bf16 MFMA peak

@@ -458,6 +458,11 @@ int mtc_aux_count_at(const mtc_desc* d, const void* acts, const int32_t* dead_id
 int mtc_densify(const mtc_desc* d, const int32_t* row_ptr, const int32_t* col_idx, const void* vals,
                 int32_t max_col, void* dense, void* stream);
 
+/* Streaming device copy (16 bytes per lane, non-temporal): the contiguous refill copy of the activation store
+ * (transcoder_activation_store.py:157-191 concatenates chunks with torch.cat) and the HBM calibration of bench.py's
+ * roofline.  bytes, dst and src multiples of 16. */
+int mtc_copy16(void* dst, const void* src, size_t bytes, void* stream);
+
 /* f1  activation-store batch assembly (transcoder_activation_store.py:184-207: DataLoader(TensorDataset(source,
  * target), batch_size, shuffle=True) -> next_batch()).  ONE launch gathers rows perm[0..n_rows) of the source buffer
  * [buffer_rows][A_s] and of the target buffer [buffer_rows][A_t] (model dtype, rows a multiple of 16 bytes) into

@@ -108,6 +108,7 @@ PROTOTYPES = {
     "mtc_aux_row_candidates": (C.c_int, [DP, P, P, P, P, P, C.c_int32, P, P]),
     "mtc_aux_count_at": (C.c_int, [DP, P, P, P, P, P, P, P]),
     "mtc_densify": (C.c_int, [DP, P, P, P, C.c_int32, P, P]),
+    "mtc_copy16": (C.c_int, [P, P, C.c_size_t, P]),
     "mtc_gather_row_pairs": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, P, P, P, P, P, P, P]),
     "mtc_collect_top_samples": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, P, P, P, P, P, P, C.c_float,
                                           C.c_int32, C.c_int32, P, P, P, P, P, P, P]),

@@ -3,6 +3,7 @@
 // device rows per batch.  Here a batch is ONE launch: a wave per output row copies row perm[i] of the source
 // buffer and of the target buffer (16-byte accesses; the rows of a pair travel together, so pairs cannot come
 // apart).  HBM-bound: reads B (A_s + A_t) s bytes of random rows, writes the same.
+#include <algorithm>
 #include "common.hpp"
 
 namespace mtc {
@@ -29,9 +30,37 @@ __global__ __launch_bounds__(256) void gather_row_pairs_kernel(int n, int row_by
         *reinterpret_cast<u32x4*>(out_t + (size_t)i * row_bytes_t + b) = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(pt + b));
 }
 
+// Streaming copy, 16 bytes per lane, 4 independent loads in flight per lane: the HBM calibration the roofline of the
+// gather / stream kernels is read against (SURVEY 8d "confirm with a copy-kernel calibration run"), and the contiguous
+// refill copy of the activation store.
+__global__ __launch_bounds__(256) void copy16_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, size_t n16) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += 4 * stride) {
+        u32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i + u * stride < n16) v[u] = __builtin_nontemporal_load(src + i + u * stride);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i + u * stride < n16) __builtin_nontemporal_store(v[u], dst + i + u * stride);
+    }
+}
+
 }  // namespace mtc
 
 using namespace mtc;
+
+extern "C" int mtc_copy16(void* dst, const void* src, size_t bytes, void* stream) {
+    MTC_REQUIRE(dst && src, "mtc_copy16: null pointer");
+    MTC_REQUIRE(bytes % 16 == 0 && ((uintptr_t)dst % 16) == 0 && ((uintptr_t)src % 16) == 0,
+                "mtc_copy16: size and pointers must be multiples of 16 bytes");
+    if (bytes == 0) return 0;
+    const size_t n16 = bytes / 16;
+    const int grid = (int)std::min<size_t>((n16 + 256 * 4 - 1) / (256 * 4), 256 * 16);
+    hipLaunchKernelGGL(copy16_kernel, dim3(grid), dim3(256), 0, as_stream(stream), reinterpret_cast<const u32x4*>(src),
+                       reinterpret_cast<u32x4*>(dst), n16);
+    return check_launch("mtc_copy16");
+}
 
 extern "C" int mtc_gather_row_pairs(int32_t dtype, int32_t n_rows, int32_t A_s, int32_t A_t, int64_t buffer_rows,
                                     const void* source_buffer, const void* target_buffer, const int64_t* perm,

@@ -78,4 +78,49 @@ for src, dst in ((f"gpurun_out/bench_aux_{tag}.json", f"profiles/{tag}_bench_aux
                  (f"gpurun_out/pmc_fused_{tag}.txt", f"profiles/{tag}_fused_pmc.txt")):
     if os.path.exists(src):
         shutil.copy(src, dst)
+# ---- one table per round: every kernel of the headline step with its algorithmic work at config #2, the
+# rocprofv3 average duration, the fraction of the bound it is priced against, and the PMC fabric traffic next to the
+# bytes it must move at least once
+B, A, D, K_TOP, S_ = 4096, 2304, 36864, 96, 2
+NNZ = K_TOP * B
+HBM_PEAK, MFMA_PEAK = 8.0e12, 2.5e15
+work = {   # kernel-name prefix -> (bound, algorithmic work, compulsory bytes or None, note)
+    "mtc::encode_bf16_mfma256p_kernel": ("mfma", 2.0 * B * A * D, B * A * S_ + D * A * S_ + B * D * S_, "2 B A D FLOP; operands once + acts written"),
+    "mtc::select_candidates_kernel": ("hbm", B * D * S_ + NNZ * 8, B * D * S_, "one read of acts + candidates out"),
+    "mtc::decode_fwd_kernel": ("hbm", NNZ * (A * S_ + 8) + 2 * B * A * S_, D * A * S_ + 3 * B * A * S_ + NNZ * 6,
+                               "gather of nnz decoder rows + target in / x_hat, g out"),
+    "mtc::fused_grad_adam_kernel": ("hbm", 6 * D * A * S_ + NNZ * A * S_ + B * A * S_, 6 * D * A * S_ + B * A * S_ + NNZ * 12,
+                                    "W_dec / moment rows read + written once, gather of nnz rows of g"),
+    "mtc::fused_enc_sliced_kernel": ("hbm", 6 * D * A * S_ + NNZ * A * S_ + B * A * S_, 6 * D * A * S_ + B * A * S_ + NNZ * 8,
+                                     "W_enc / moment rows read + written once, gather of nnz rows of x (L2-resident slices)"),
+    "mtc::csc_": ("latency", NNZ * 16, NNZ * 16, "CSC build: count / scan / fill / sort, summed"),
+    "mtc::colsum_": ("hbm", B * A * S_, B * A * S_, "db_dec column sums, both launches"),
+    "mtc::select_": ("latency", 0, 0, "exact select on the compact candidate matrix (hist / scan / rowsub / tail / fill), summed"),
+}
+stats = {}
+for r in csv.DictReader(open(f"profiles/{tag}_kernel_stats.csv")):
+    stats[r["Name"].split("(")[0].replace("void ", "")] = (float(r["AverageNs"]), int(r["Calls"]), float(r["TotalDurationNs"]))
+steps = max((c for n, (a, c, t) in stats.items() if n.startswith("mtc::encode_bf16_mfma256p_kernel")), default=1)
+rows = []
+for prefix, (bound, alg, comp, note) in work.items():
+    names = [n for n in stats if n.startswith(prefix) and not (prefix == "mtc::select_" and n.startswith("mtc::select_candidates"))]
+    if not names:
+        continue
+    per_step_us = sum(stats[n][2] for n in names) / steps / 1e3
+    traffic = sum(kernels.get(n, {}).get("hbm_bytes_per_launch", 0) * stats[n][1] / steps for n in names) or None
+    row = {"kernel": prefix + ("*" if len(names) > 1 or names[0] != prefix else ""), "launches_per_step": round(sum(stats[n][1] for n in names) / steps, 2),
+           "us_per_step": round(per_step_us, 1), "bound": bound, "note": note}
+    if bound == "mfma":
+        row.update(algorithmic_flop=alg, achieved_TFLOPs=round(alg / per_step_us / 1e6, 1), frac_of_peak=round(alg / per_step_us / 1e-6 / MFMA_PEAK, 3))
+    elif bound == "hbm":
+        row.update(algorithmic_bytes=int(alg), achieved_TBps=round(alg / per_step_us / 1e6, 2), frac_of_peak=round(alg / (per_step_us * 1e-6) / HBM_PEAK, 3),
+                   compulsory_bytes=int(comp), frac_compulsory=round(comp / (per_step_us * 1e-6) / HBM_PEAK, 3))
+    if traffic and comp:
+        row.update(pmc_fabric_bytes=int(traffic), traffic_over_compulsory=round(traffic / comp, 2))
+    rows.append(row)
+json.dump({"workload": "gemma2-2b bf16 (config #2): B 4096, A 2304, D 36864, k 96", "peaks": {"hbm_Bps": HBM_PEAK, "mfma_bf16_FLOPs": MFMA_PEAK},
+           "sources": [f"profiles/{tag}_kernel_stats.csv (rocprofv3 --kernel-trace --stats)", f"profiles/{tag}_pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE)"],
+           "definitions": "algorithmic = SURVEY 8d per-unit work (row gathers counted per selected entry); compulsory = bytes that must "
+                          "cross HBM at least once; pmc_fabric_bytes = L2's memory-side traffic (Infinity Cache hits included)",
+           "kernels": rows}, open(f"profiles/{tag}_roofline.json", "w"), indent=1)
 print("profiles updated for", tag)
