@@ -73,6 +73,16 @@ int mtc_row_normalize(const mtc_desc* d, const void* x, void* x_norm, void* mean
 int mtc_encode_fwd(const mtc_desc* d, const void* x, const void* W_encT, const void* b_enc,
                    void* acts, void* stream);
 
+/* The training loop's encoder: the same launch also MARKS, per batch row and 128-feature block, which 16-feature
+ * granules may hold an activation >= the select's carried bound carry[0] (mtc_select_global_topk_carry): the first pass
+ * of sae.py:176-182's topk over the B*D activations happens in the epilogue that holds them anyway, and the select's
+ * candidate pass (mtc_select_global_topk_carry_marked) reads only the flagged granules instead of all of acts.
+ * marks: mtc_encode_marks_bytes(d) bytes = uint8 [B][ceil(D/128)] + the bound they were made for; 0 bytes = this shape /
+ * dtype does not run the marking kernel (small problems, fp32): use mtc_encode_fwd and pass marks = NULL to the select. */
+size_t mtc_encode_marks_bytes(const mtc_desc* d);
+int mtc_encode_fwd_marked(const mtc_desc* d, const void* x, const void* W_encT, const void* b_enc,
+                          void* acts, const uint32_t* carry, void* marks, void* stream);
+
 /* a4 / a15  eval-mode encode (sae.py:189-191 inside encode, sae.py:363-387): the same encoder with
  * where(acts > threshold, acts, 0) applied in its epilogue, so the dense feature tensor `feats` [B][D] the API
  * returns is written once and never re-read.  threshold: device scalar in the model dtype (the module's buffer). */
@@ -148,6 +158,14 @@ int mtc_select_global_topk_carry_ema(const mtc_desc* d, const void* acts, uint32
                                      mtc_select_state* st, int32_t* row_ptr, int32_t* col_idx,
                                      void* vals, void* threshold, float ema_lr, void* stream);
 
+/* ... with the encoder's marks (mtc_encode_fwd_marked; NULL = stream all of acts).  Marks made for another bound than the
+ * one carried now are ignored; the result is the same bit for bit either way. */
+int mtc_select_global_topk_carry_marked(const mtc_desc* d, const void* acts, uint32_t k_total,
+                                        void* workspace, size_t workspace_bytes, uint32_t* carry,
+                                        mtc_select_state* st, int32_t* row_ptr, int32_t* col_idx,
+                                        void* vals, void* threshold, float ema_lr, const void* marks,
+                                        void* stream);
+
 /* Helpers of the feature-sharded caller (no counterpart in the single-process reference; each replaces a
  * handful of tiny tensor ops between two collectives):
  *   mtc_select_offsets_sharded : mtc_select_offsets with the tie order of a sharded dictionary -- ties are
@@ -189,7 +207,8 @@ size_t mtc_select_sharded_xbuf_words(void);
 size_t mtc_select_sharded_full_bins(void);
 int mtc_select_sharded_begin(const mtc_desc* d, const void* acts, uint32_t k_total, void* workspace,
                              size_t workspace_bytes, uint32_t* carry /* NULL for fp32 */, mtc_select_state* st,
-                             uint32_t* xbuf, uint32_t* hist_full /* NULL for fp32 */, uint32_t* pack, void* stream);
+                             uint32_t* xbuf, uint32_t* hist_full /* NULL for fp32 */, uint32_t* pack,
+                             const void* marks /* mtc_encode_fwd_marked's, or NULL */, void* stream);
 int mtc_select_sharded_window(const mtc_desc* d, const void* acts, uint32_t k_total, uint32_t* carry,
                               mtc_select_state* st, const uint32_t* xbuf, uint32_t* hist_full, void* stream);
 int mtc_select_sharded_counts(const mtc_desc* d, const void* acts, uint32_t k_total, void* workspace,

@@ -37,6 +37,8 @@ PROTOTYPES = {
     "mtc_version": (C.c_int, []),
     "mtc_row_normalize": (C.c_int, [DP, P, P, P, P, P]),
     "mtc_encode_fwd": (C.c_int, [DP, P, P, P, P, P]),
+    "mtc_encode_marks_bytes": (C.c_size_t, [DP]),
+    "mtc_encode_fwd_marked": (C.c_int, [DP, P, P, P, P, P, P, P]),
     "mtc_encode_threshold_infer": (C.c_int, [DP, P, P, P, P, P, P]),
     "mtc_encode_set_tile": (C.c_int, [C.c_int]),
     "mtc_select_levels": (C.c_int, [DP]),
@@ -53,12 +55,13 @@ PROTOTYPES = {
     "mtc_select_carry_workspace_bytes": (C.c_size_t, [DP]),
     "mtc_select_global_topk_carry": (C.c_int, [DP, P, C.c_uint32, P, C.c_size_t, P, P, P, P, P, P]),
     "mtc_select_global_topk_carry_ema": (C.c_int, [DP, P, C.c_uint32, P, C.c_size_t, P, P, P, P, P, P, C.c_float, P]),
+    "mtc_select_global_topk_carry_marked": (C.c_int, [DP, P, C.c_uint32, P, C.c_size_t, P, P, P, P, P, P, C.c_float, P, P]),
     "mtc_select_offsets_sharded": (C.c_int, [DP, P, P, C.c_int32, C.c_int32, C.c_int32, P, P, P, P, P]),
     "mtc_select_pack_minmax": (C.c_int, [P, P, P]),
     "mtc_select_sharded_workspace_bytes": (C.c_size_t, [DP]),
     "mtc_select_sharded_xbuf_words": (C.c_size_t, []),
     "mtc_select_sharded_full_bins": (C.c_size_t, []),
-    "mtc_select_sharded_begin": (C.c_int, [DP, P, C.c_uint32, P, C.c_size_t, P, P, P, P, P, P]),
+    "mtc_select_sharded_begin": (C.c_int, [DP, P, C.c_uint32, P, C.c_size_t, P, P, P, P, P, P, P]),
     "mtc_select_sharded_window": (C.c_int, [DP, P, C.c_uint32, P, P, P, P, P]),
     "mtc_select_sharded_counts": (C.c_int, [DP, P, C.c_uint32, P, P, P, P, P, P]),
     "mtc_select_sharded_finish": (C.c_int, [DP, P, P, P, P, P, C.c_int32, C.c_int32, P, P, P, P, C.c_float, P]),

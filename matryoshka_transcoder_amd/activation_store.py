@@ -147,6 +147,9 @@ class TranscoderActivationsStore:
     def _gather_pairs(self, idx: torch.Tensor):
         src, tgt = self.source_buffer, self.target_buffer
         if not src.is_cuda:
+            # host buffer (cfg["device"] = "cpu"): plain indexing.  Data plumbing only -- nothing of the hot path computes
+            # here (a CPU batch handed to MatryoshkaTranscoder raises MtcError); the CPU test-suite checks the store's
+            # bookkeeping (buffer refill, permutation, short last batch, aligned pairs) through this branch
             return src.index_select(0, idx), tgt.index_select(0, idx)
         import ctypes as C
         from . import _lib

@@ -614,12 +614,28 @@ constexpr int P256_LDS = 2 * 4 * HALF_BYTES + 8 * STG_BYTES;     // 160 KiB: the
 #define PFENCE(i) PHASE_FENCE()
 #endif
 
-template <bool THR>
+// MARK = 1 (training loop): the epilogue also leaves, per batch row and per 128-feature block, one byte whose bit i says
+// "features [16 i, 16 i + 16) of this block may hold an activation >= the select's carried bound" (carry[0], the
+// lower bound of this step's TopK threshold; select.hip).  The select's candidate pass then reads only the flagged
+// 32-byte granules of the activations (~8 % of them) instead of all B * D: the first pass over the activations happens
+// here, on the packed values the epilogue holds anyway (one packed max + a compare per 4 values, two cross-lane ORs and
+// one byte store per 16 rows x 128 features).  marks: uint8 [M][ceil(N / 128)] + one uint32 behind it (4-byte aligned)
+// that records the bound the marks were made for -- a select running with another bound ignores them.
+template <bool THR, bool MARK = false>
 __global__ __launch_bounds__(512, 1) void encode_bf16_mfma256p_kernel(const u16* __restrict__ X, const u16* __restrict__ Wt,
                                                                       const u16* __restrict__ bias, u16* __restrict__ acts,
-                                                                      int M, int N, int K, int mt, int nt, const void* __restrict__ thr) {
+                                                                      int M, int N, int K, int mt, int nt, const void* __restrict__ thr,
+                                                                      const uint32_t* __restrict__ carry = nullptr,
+                                                                      unsigned char* __restrict__ marks = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
+    uint32_t g16 = 0x10000u;                                                     // "nothing is a candidate"
+    const int nblk = (N + 127) >> 7;
+    if constexpr (MARK) {
+        const uint32_t guess = carry[0];
+        if (guess != 0) g16 = guess >> 16;
+        if (blockIdx.x == 0 && tid == 0) *reinterpret_cast<uint32_t*>(marks + ((((size_t)M * nblk) + 3) & ~(size_t)3)) = guess;
+    }
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 2, wc = wid & 3;
     // ---- this workgroup's tiles: logical ids first, first + stride, ... (count of them)
@@ -794,6 +810,7 @@ __global__ __launch_bounds__(512, 1) void encode_bf16_mfma256p_kernel(const u16*
         for (int j = 0; j < 4; ++j) {
             // lane holds features i*16 + fq*4 + (0..3) of batch row j*16 + fr: 8 bytes into row fr of the staging block,
             // 16-byte chunk (2 i + fq/2) XOR-ed with the row (conflict-free ds_write_b64 / ds_read_b128)
+            uint32_t mark = 0;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const f32x4 v = acc[i][j];
@@ -802,6 +819,21 @@ __global__ __launch_bounds__(512, 1) void encode_bf16_mfma256p_kernel(const u16*
                 o.y = bias_relu_pack2<THR>(v[2], v[3], bf16_bits_to_f32(bb[i].y & 0xffffu), bf16_bits_to_f32(bb[i].y >> 16), fl);
                 *reinterpret_cast<uint2*>(stg + fr * 256 + ((((i << 1) | (fq >> 1)) ^ fr) << 4) + ((fq & 1) << 3)) = o;
                 acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (MARK) {
+                    typedef __attribute__((ext_vector_type(2))) unsigned short us2v;
+                    const uint32_t ox = o.x, oy = o.y;
+                    const us2v m2 = __builtin_elementwise_max(__builtin_bit_cast(us2v, ox), __builtin_bit_cast(us2v, oy));
+                    const uint32_t mx = max((uint32_t)m2.x, (uint32_t)m2.y);
+                    // (columns beyond N hold products of clamped weight rows: never candidates)
+                    mark |= (mx >= g16 && fcol + i * 16 + fq * 4 < N) ? (1u << i) : 0u;
+                }
+            }
+            if constexpr (MARK) {
+                // the 16 features of bit i sit in the four lanes fr, fr + 16, fr + 32, fr + 48
+                mark |= (uint32_t)__shfl_xor((int)mark, 16, 64);
+                mark |= (uint32_t)__shfl_xor((int)mark, 32, 64);
+                const int b = brow + j * 16 + fr;
+                if (fq == 0 && b < M && fcol < N) marks[(size_t)b * nblk + (fcol >> 7)] = (unsigned char)mark;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // wave-private region: no barrier needed
 #pragma unroll
@@ -931,7 +963,7 @@ static void encode_options_once() {
     if (g_f32_generic < 0) g_f32_generic = getenv("MTC_ENCODE_F32_GENERIC") ? 1 : 0;
 }
 constexpr int MAX_DEV = 64;
-static bool g_attr_done[9][MAX_DEV];
+static bool g_attr_done[10][MAX_DEV];
 static int g_cus[MAX_DEV];
 static void lds_opt_in(int which, const void* fn, int lds) {
     int dev = 0;
@@ -965,8 +997,16 @@ extern "C" int mtc_encode_set_tile(int tile) {
     return prev;
 }
 
+// does this shape run the persistent 256 x 256 kernel (the one that can mark candidate granules)?
+static bool uses_persistent(const mtc_desc* d) {
+    encode_options_once();
+    const int M = d->B, N = d->D, K = d->A_s;
+    const int big_tiles = ((M + B2M - 1) / B2M) * ((N + B2N - 1) / B2N);
+    return d->dtype == MTC_BF16 && (K % BK) == 0 && g_tile != 3 && ((big_tiles >= 512 && g_tile != 1) || g_tile == 2);
+}
+
 static int encode_impl(const mtc_desc* d, const void* x, const void* W_encT, const void* b_enc, const void* thr,
-                       void* acts, void* stream) {
+                       void* acts, void* stream, const uint32_t* carry = nullptr, unsigned char* marks = nullptr) {
     const int M = d->B, N = d->D, K = d->A_s;
     encode_options_once();
     if (d->dtype == MTC_F32 && (K % BK32) == 0 && !g_f32_generic) {
@@ -991,13 +1031,19 @@ static int encode_impl(const mtc_desc* d, const void* x, const void* W_encT, con
         const int mt = (M + B2M - 1) / B2M, nt = (N + B2N - 1) / B2N;
         const int grid = min(mt * nt, cu_count());                               // one persistent workgroup per CU
         if (thr) {
-            lds_opt_in(3, reinterpret_cast<const void*>(encode_bf16_mfma256p_kernel<true>), P256_LDS);
-            hipLaunchKernelGGL(encode_bf16_mfma256p_kernel<true>, dim3(grid), dim3(512), P256_LDS, as_stream(stream),
-                               (const u16*)x, (const u16*)W_encT, (const u16*)b_enc, (u16*)acts, M, N, K, mt, nt, thr);
+            lds_opt_in(3, reinterpret_cast<const void*>(encode_bf16_mfma256p_kernel<true, false>), P256_LDS);
+            hipLaunchKernelGGL((encode_bf16_mfma256p_kernel<true, false>), dim3(grid), dim3(512), P256_LDS, as_stream(stream),
+                               (const u16*)x, (const u16*)W_encT, (const u16*)b_enc, (u16*)acts, M, N, K, mt, nt, thr,
+                               (const uint32_t*)nullptr, (unsigned char*)nullptr);
+        } else if (carry && marks) {
+            lds_opt_in(9, reinterpret_cast<const void*>(encode_bf16_mfma256p_kernel<false, true>), P256_LDS);
+            hipLaunchKernelGGL((encode_bf16_mfma256p_kernel<false, true>), dim3(grid), dim3(512), P256_LDS, as_stream(stream),
+                               (const u16*)x, (const u16*)W_encT, (const u16*)b_enc, (u16*)acts, M, N, K, mt, nt, thr, carry, marks);
         } else {
-            lds_opt_in(4, reinterpret_cast<const void*>(encode_bf16_mfma256p_kernel<false>), P256_LDS);
-            hipLaunchKernelGGL(encode_bf16_mfma256p_kernel<false>, dim3(grid), dim3(512), P256_LDS, as_stream(stream),
-                               (const u16*)x, (const u16*)W_encT, (const u16*)b_enc, (u16*)acts, M, N, K, mt, nt, thr);
+            lds_opt_in(4, reinterpret_cast<const void*>(encode_bf16_mfma256p_kernel<false, false>), P256_LDS);
+            hipLaunchKernelGGL((encode_bf16_mfma256p_kernel<false, false>), dim3(grid), dim3(512), P256_LDS, as_stream(stream),
+                               (const u16*)x, (const u16*)W_encT, (const u16*)b_enc, (u16*)acts, M, N, K, mt, nt, thr,
+                               (const uint32_t*)nullptr, (unsigned char*)nullptr);
         }
     } else if (d->dtype == MTC_BF16 && (K % BK) == 0) {
         const int lds = 2 * 2 * TILE_BYTES;
@@ -1023,6 +1069,19 @@ extern "C" int mtc_encode_fwd(const mtc_desc* d, const void* x, const void* W_en
     if (check_desc(d, "mtc_encode_fwd")) return -1;
     MTC_REQUIRE(x && W_encT && b_enc && acts, "mtc_encode_fwd: null pointer");
     return encode_impl(d, x, W_encT, b_enc, nullptr, acts, stream);
+}
+
+extern "C" size_t mtc_encode_marks_bytes(const mtc_desc* d) {
+    if (!d || !uses_persistent(d)) return 0;
+    return ((((size_t)d->B * ((d->D + 127) >> 7)) + 3) & ~(size_t)3) + 4;
+}
+
+extern "C" int mtc_encode_fwd_marked(const mtc_desc* d, const void* x, const void* W_encT, const void* b_enc, void* acts,
+                                     const uint32_t* carry, void* marks, void* stream) {
+    if (check_desc(d, "mtc_encode_fwd_marked")) return -1;
+    MTC_REQUIRE(x && W_encT && b_enc && acts && carry && marks, "mtc_encode_fwd_marked: null pointer");
+    MTC_REQUIRE(uses_persistent(d), "mtc_encode_fwd_marked: this shape does not run the marking kernel (mtc_encode_marks_bytes() = 0)");
+    return encode_impl(d, x, W_encT, b_enc, nullptr, acts, stream, carry, reinterpret_cast<unsigned char*>(marks));
 }
 
 extern "C" int mtc_encode_threshold_infer(const mtc_desc* d, const void* x, const void* W_encT, const void* b_enc,

@@ -527,10 +527,16 @@ template <> __device__ __forceinline__ bool chunk_may_hold<MTC_F32>(const Raw<MT
 // than a wave's worth, 64 queued chunks are examined exactly, one per lane, and their candidates are written out in
 // order.  The exact test / ordered compaction therefore runs once per ~25 loads instead of once per load.
 constexpr int CAND_QCAP = 128;
+// marks (optional; written by the encoder's epilogue, see encode_bf16_mfma256p_kernel<.., MARK>): uint8 [B][ceil(D / 128)],
+// bit i of a byte = "features [16 i, 16 i + 16) of that 128-feature block may hold an entry >= the bound", followed by
+// the bound they were made for.  When that bound is the one carried now, only the flagged 32-byte granules are read
+// (the queue then holds chunk numbers and the data is fetched when a batch of 64 is examined); otherwise -- no marks,
+// another bound -- the row is streamed.  Same candidates, same order either way.
 template <int DT>
 __global__ __launch_bounds__(256) void select_candidates_kernel(const void* __restrict__ acts, int B, int D, int C,
                                                                 const uint32_t* __restrict__ carry, void* __restrict__ cand_vals,
-                                                                int32_t* __restrict__ cand_cols, uint32_t* __restrict__ cand_cnt) {
+                                                                int32_t* __restrict__ cand_cols, uint32_t* __restrict__ cand_cnt,
+                                                                const unsigned char* __restrict__ marks) {
     typedef typename DType<DT>::T T;
     constexpr int U = DT == MTC_BF16 ? 8 : 4;
     __shared__ Raw<DT> q_raw[4][CAND_QCAP];
@@ -547,6 +553,9 @@ __global__ __launch_bounds__(256) void select_candidates_kernel(const void* __re
     const int nch = D >> 3;
     uint32_t out = 0;
     int qn = 0;                                          // queued chunks (wave-uniform)
+    const int nblk = (D + 127) >> 7;
+    const bool marked = marks != nullptr &&
+                        *reinterpret_cast<const uint32_t*>(marks + ((((size_t)B * nblk) + 3) & ~(size_t)3)) == guess;   // uniform
 
     // exact pass over queued chunks [0, qn): one chunk per lane, candidates leave in (chunk, element) order
     auto drain = [&]() {
@@ -555,9 +564,9 @@ __global__ __launch_bounds__(256) void select_candidates_kernel(const void* __re
             float v[8];
             uint32_t m = 0;
             int c = 0;
-            if (e < qn) {
-                const Raw<DT> r = q_raw[w][e];
-                c = q_chunk[w][e];
+            if (e < qn) c = q_chunk[w][e];
+            if (e < qn && c >= 0) {
+                const Raw<DT> r = marked ? load_raw_nt<DT>(acts, base + (size_t)c * 8) : q_raw[w][e];
                 unpack(r, v);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
@@ -592,6 +601,47 @@ __global__ __launch_bounds__(256) void select_candidates_kernel(const void* __re
         qn = 0;
     };
 
+    if (marked) {
+        // one mark byte per lane and round (128 features = 16 chunks); flagged granules queue up as two chunk numbers
+        // each, in (block, bit) order = column order
+        const unsigned char* mrow = marks + (size_t)row * nblk;
+        for (int b0 = 0; b0 < nblk; b0 += 64) {
+            const int blk = b0 + lane;
+            uint32_t byte = blk < nblk ? (uint32_t)mrow[blk] : 0u;
+            const uint32_t n2 = 2u * __popc(byte);                         // chunks this lane queues
+            // exclusive prefix over the lanes (n2 <= 16: five bit planes)
+            uint32_t at = 0, tot = 0;
+#pragma unroll
+            for (int p = 1; p < 5; ++p) {
+                const uint64_t bp = __ballot((n2 >> p) & 1u);
+                at += (mbcnt64(bp) << p);
+                tot += ((uint32_t)__popcll(bp) << p);
+            }
+            if (tot == 0) continue;                                        // wave-uniform
+            // a round can queue up to 1024 chunks: hand them over in slices the queue has room for
+            uint32_t done = 0;                                             // chunks of this round already queued (uniform)
+            while (done < tot) {
+                const uint32_t room = (uint32_t)(CAND_QCAP - qn);
+                const uint32_t upto = min(tot, done + room);               // queue chunks [done, upto) of the round
+                uint32_t k = at;                                           // running index of this lane's chunks
+                uint32_t bits = byte;
+                while (bits) {
+                    const int bit = __ffs(bits) - 1;
+                    bits &= bits - 1;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h, ++k)
+                        if (k >= done && k < upto) {
+                            const int c = blk * 16 + bit * 2 + h;
+                            q_chunk[w][qn + (int)(k - done)] = c < nch ? c : -1;      // (a granule's second half may lie beyond D)
+                        }
+                }
+                qn += (int)(upto - done);
+                done = upto;
+                if (qn > CAND_QCAP - 64 || done < tot) drain();
+            }
+        }
+        drain();
+    } else {
     Raw<DT> nxt[U];
 #pragma unroll
     for (int u = 0; u < U; ++u)
@@ -621,6 +671,7 @@ __global__ __launch_bounds__(256) void select_candidates_kernel(const void* __re
         }
     }
     drain();
+    }
     // zero the unused tail of the compact row (the select passes treat 0 as "not a candidate")
     const uint32_t n_kept = min(out, (uint32_t)C);
     const uint32_t al = (n_kept + 7u) & ~7u;
@@ -1318,6 +1369,14 @@ extern "C" int mtc_select_global_topk_carry_ema(const mtc_desc* d, const void* a
                                                 size_t workspace_bytes, uint32_t* carry, mtc_select_state* st,
                                                 int32_t* row_ptr, int32_t* col_idx, void* vals, void* threshold,
                                                 float ema_lr, void* stream) {
+    return mtc_select_global_topk_carry_marked(d, acts, k_total, workspace, workspace_bytes, carry, st, row_ptr, col_idx, vals,
+                                               threshold, ema_lr, nullptr, stream);
+}
+
+extern "C" int mtc_select_global_topk_carry_marked(const mtc_desc* d, const void* acts, uint32_t k_total, void* workspace,
+                                                   size_t workspace_bytes, uint32_t* carry, mtc_select_state* st,
+                                                   int32_t* row_ptr, int32_t* col_idx, void* vals, void* threshold,
+                                                   float ema_lr, const void* marks, void* stream) {
     if (check_desc(d, "mtc_select_global_topk_carry")) return -1;
     MTC_REQUIRE(acts && workspace && carry && st && row_ptr && col_idx && vals, "mtc_select_global_topk_carry: null pointer");
     MTC_REQUIRE(workspace_bytes >= mtc_select_carry_workspace_bytes(d),
@@ -1342,7 +1401,7 @@ extern "C" int mtc_select_global_topk_carry_ema(const mtc_desc* d, const void* a
     int rc;
     // one pass over acts with the carried bound, then the verdict (flag) for the launches below
     DISPATCH_DT(d->dtype, select_candidates_kernel, dim3((d->B + 3) / 4), dim3(256), 0, s, acts, d->B, d->D, C, carry,
-                (void*)cand_vals, cand_cols, cand_cnt);
+                (void*)cand_vals, cand_cols, cand_cnt, reinterpret_cast<const unsigned char*>(marks));
     hipLaunchKernelGGL(select_carry_decide_kernel, dim3(1), dim3(1024), 0, s, carry, cand_cnt, d->B, C, k_total, st, hist);
     if ((rc = check_launch("mtc_select_global_topk_carry"))) return rc;
     // each streaming pass is ONE launch that reads the compact matrix if flag == 1 and acts if flag == 0 (grid sized for
@@ -1420,7 +1479,7 @@ extern "C" size_t mtc_select_sharded_full_bins(void) { return FULL_BINS; }
 
 extern "C" int mtc_select_sharded_begin(const mtc_desc* d, const void* acts, uint32_t k_total, void* workspace,
                                         size_t workspace_bytes, uint32_t* carry, mtc_select_state* st, uint32_t* xbuf,
-                                        uint32_t* hist_full, uint32_t* pack, void* stream) {
+                                        uint32_t* hist_full, uint32_t* pack, const void* marks, void* stream) {
     if (check_desc(d, "mtc_select_sharded_begin")) return -1;
     MTC_REQUIRE(acts && workspace && st && xbuf && pack, "mtc_select_sharded_begin: null pointer");
     MTC_REQUIRE(workspace_bytes >= mtc_select_sharded_workspace_bytes(d), "mtc_select_sharded_begin: workspace too small (%zu < %zu)",
@@ -1434,7 +1493,8 @@ extern "C" int mtc_select_sharded_begin(const mtc_desc* d, const void* acts, uin
     if (d->dtype == MTC_BF16) {
         // one pass over the activations with the carried bound, then the window histogram of what it kept
         hipLaunchKernelGGL(select_candidates_kernel<MTC_BF16>, dim3((d->B + 3) / 4), dim3(256), 0, s, acts, d->B, d->D, w.C,
-                           (const uint32_t*)carry, (void*)w.cand_vals, w.cand_cols, w.cand_cnt);
+                           (const uint32_t*)carry, (void*)w.cand_vals, w.cand_cols, w.cand_cnt,
+                           reinterpret_cast<const unsigned char*>(marks));
         hipLaunchKernelGGL(shard_window_hist_kernel, dim3(std::min(256, (d->B + 3) / 4)), dim3(256), 0, s,
                            (const u16*)w.cand_vals, (const uint32_t*)w.cand_cnt, d->B, w.C, (const uint32_t*)carry, xbuf);
     }

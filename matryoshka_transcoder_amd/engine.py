@@ -111,6 +111,7 @@ class HotPath:
         self.code = dtype_code(dtype)
         self.unit_norm = bool(unit_norm)
         self._carry = {}                 # device -> 8 x uint32 carried lower bound of the TopK threshold
+        self.use_marks = True            # encoder epilogue marks candidate granules for the select (tests switch it off to A/B)
         self._pinned = {}                # device -> ring of pinned int32[2] (dead-list counts on their way to the host)
 
     def desc(self, B: int):
@@ -126,10 +127,21 @@ class HotPath:
         return xn, mean, std
 
     # ------------------------------------------------------------------ a3 dense part
-    def encode(self, d, x_norm, W_encT, b_enc):
+    def encode(self, d, x_norm, W_encT, b_enc, mark_for=None):
+        """a3 dense part.  mark_for = the carried-bound state of the select that will follow (training loop): the launch
+        then also marks the granules that may hold TopK candidates (mtc_encode_fwd_marked) and the marks travel with the
+        returned tensor (`acts._mtc_marks`) to select_topk / the sharded select; shapes that do not run the marking
+        kernel return plain activations."""
         _need(W_encT, "W_encT", self.dtype, (self.D, self.A_s))
         _need(b_enc, "b_enc", self.dtype, (self.D,))
         acts = torch.empty(d.B, self.D, dtype=self.dtype, device=x_norm.device)
+        nbytes = self.lib.mtc_encode_marks_bytes(C.byref(d)) if mark_for is not None and self.use_marks else 0
+        if nbytes:
+            marks = torch.empty(nbytes, dtype=torch.uint8, device=x_norm.device)
+            check(self.lib.mtc_encode_fwd_marked(C.byref(d), _p(x_norm), _p(W_encT), _p(b_enc), _p(acts), _p(mark_for), _p(marks),
+                                                 _stream()), "mtc_encode_fwd_marked")
+            acts._mtc_marks = marks
+            return acts
         check(self.lib.mtc_encode_fwd(C.byref(d), _p(x_norm), _p(W_encT), _p(b_enc), _p(acts), _stream()), "mtc_encode_fwd")
         return acts
 
@@ -165,9 +177,10 @@ class HotPath:
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
             if threshold is not None:
                 _need(threshold, "threshold", self.dtype)
-            check(self.lib.mtc_select_global_topk_carry_ema(C.byref(d), _p(acts), int(k_total), _p(ws), ws_bytes,
-                                                            _p(self.carry_state(dev)), _p(st), _p(row_ptr), _p(col_idx),
-                                                            _p(vals), _p(threshold), float(ema_lr), _stream()),
+            check(self.lib.mtc_select_global_topk_carry_marked(C.byref(d), _p(acts), int(k_total), _p(ws), ws_bytes,
+                                                               _p(self.carry_state(dev)), _p(st), _p(row_ptr), _p(col_idx),
+                                                               _p(vals), _p(threshold), float(ema_lr),
+                                                               _p(getattr(acts, "_mtc_marks", None)), _stream()),
                   "mtc_select_global_topk_carry")
             return Selection(st, row_ptr, col_idx, vals)
         ws_bytes = self.lib.mtc_select_workspace_bytes(C.byref(d))

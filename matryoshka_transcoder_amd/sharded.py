@@ -308,6 +308,9 @@ class ShardedMatryoshkaTranscoder(MatryoshkaTranscoder):
             self._sel_bufs[key] = bufs
         return bufs
 
+    def _select_carry(self, hp, d, device):
+        return self._select_buffers(hp, d)["carry"] if self.dtype == torch.bfloat16 else None
+
     def _select(self, hp, d, acts, training: bool) -> Selection:
         """sae.py:176-188 over the sharded dictionary: mtc_select_sharded_* (include/mtc.h) with three fixed-shape
         collectives; the carried bound of the single-GPU select is used here too (bf16), ties are granted in ascending
@@ -323,7 +326,8 @@ class ShardedMatryoshkaTranscoder(MatryoshkaTranscoder):
         ws, xbuf, hist_full, pack, all_pack = bf["ws"], bf["xbuf"], bf["hist_full"], bf["pack"], bf["all_pack"]
         carry = bf["carry"] if bf16 else None
         check(lib.mtc_select_sharded_begin(C.byref(d), _p(acts), k_total, _p(ws), bf["ws_bytes"], _p(carry), _p(st), _p(xbuf),
-                                           _p(hist_full) if bf16 else None, _p(pack), s), "mtc_select_sharded_begin")
+                                           _p(hist_full) if bf16 else None, _p(pack), _p(getattr(acts, "_mtc_marks", None)), s),
+              "mtc_select_sharded_begin")
         if bf16:
             comm.all_reduce(xbuf[:4104], tag="select window (all-reduce)")
             check(lib.mtc_select_sharded_window(C.byref(d), _p(acts), k_total, _p(carry), _p(st), _p(xbuf), _p(hist_full), s),

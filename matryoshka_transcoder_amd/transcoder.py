@@ -218,6 +218,10 @@ class MatryoshkaTranscoder(nn.Module):
             self.threshold.copy_((1 - lr) * self.threshold + lr * acts_topk[pos].min())
 
     # ------------------------------------------------------------------ the fused chain
+    def _select_carry(self, hp, d, device):
+        """The carried-bound state the training select of this model runs with (what the encoder marks candidates for)."""
+        return hp.carry_state(device)
+
     def _select(self, hp, d, acts, training: bool) -> Selection:
         if training:
             # threshold EMA (a5) rides in the select's tail launch
@@ -293,7 +297,8 @@ class MatryoshkaTranscoder(nn.Module):
         else:
             xn, mean, std = x_source, None, None
             self.x_mean = self.x_std = None
-        acts = hp.encode(d, xn, self._w_encT(W_enc), b_enc.contiguous())
+        acts = hp.encode(d, xn, self._w_encT(W_enc), b_enc.contiguous(),
+                         mark_for=self._select_carry(hp, d, x_source.device) if self.training else None)
         sel = self._select(hp, d, acts, self.training)
         if self._cnt.device != x_source.device or self._cnt.dtype != torch.float32:
             self._cnt = self._cnt.to(device=x_source.device, dtype=torch.float32)

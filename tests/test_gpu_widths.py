@@ -324,10 +324,10 @@ def test_medium_fixture_through_hip_path(tag, gpu_lib):
 
 
 # ------------------------------------------------------------------ (e) BASELINE configs #4 / #5 at full size
-@pytest.mark.parametrize("workload", ["gemma2-9b", "gemma2-27b"])
+@pytest.mark.parametrize("workload", ["gemma2-9b", "gemma2-27b", "gemma2-27b-2x"])
 def test_full_size_properties_large_models(workload, gpu_lib):
-    """BASELINE configs #4 (A 3584, D 57344, k 128, B 8192, 6 groups) and #5 (A 4608, D 73728, k 184, B 16384) at full
-    size on one GPU: size-independent invariants of the select / decode / step through the NC = 7 / 9 kernels, and the
+    """BASELINE configs #4 (A 3584, D 57344, k 128, B 8192, 6 groups) and #5 (A 4608, D 73728, k 184, B 16384; and its
+    2x stress dictionary D 147456: 15 GB of parameters + moments + activations) at full size on one GPU: size-independent invariants of the select / decode / step through the NC = 7 / 9 kernels, and the
     fused step against the autograd path (bit-identical weights)."""
     import bench
     from matryoshka_transcoder_amd.training import FusedAdam
