@@ -30,20 +30,15 @@ __global__ __launch_bounds__(256) void gather_row_pairs_kernel(int n, int row_by
         *reinterpret_cast<u32x4*>(out_t + (size_t)i * row_bytes_t + b) = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(pt + b));
 }
 
-// Streaming copy, 16 bytes per lane, 4 independent loads in flight per lane: the HBM calibration the roofline of the
-// gather / stream kernels is read against (SURVEY 8d "confirm with a copy-kernel calibration run"), and the contiguous
-// refill copy of the activation store.
+// Streaming copy, 16 bytes per lane: the HBM calibration the roofline of the gather / stream kernels is read against
+// (SURVEY 8d "confirm with a copy-kernel calibration run"), and the contiguous refill copy of the activation store.
+// ONE 16-byte element per thread and as many workgroups as that takes: measured on a 1 GiB copy (tools/copy_exp.py,
+// round 3), workgroups that walk the buffer with a grid-wide stride reach 4.2-5.1 TB/s (read + write) at 1 K-64 K
+// workgroups, whatever the unroll or cache policy, while consecutive workgroups on consecutive 4 KiB reach 6.2 (plain) -
+// 6.7 TB/s (non-temporal loads and stores): neighbouring workgroups then share DRAM pages.
 __global__ __launch_bounds__(256) void copy16_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, size_t n16) {
-    const size_t stride = (size_t)gridDim.x * 256;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += 4 * stride) {
-        u32x4 v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (i + u * stride < n16) v[u] = __builtin_nontemporal_load(src + i + u * stride);
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (i + u * stride < n16) __builtin_nontemporal_store(v[u], dst + i + u * stride);
-    }
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
 }
 
 }  // namespace mtc
@@ -56,7 +51,8 @@ extern "C" int mtc_copy16(void* dst, const void* src, size_t bytes, void* stream
                 "mtc_copy16: size and pointers must be multiples of 16 bytes");
     if (bytes == 0) return 0;
     const size_t n16 = bytes / 16;
-    const int grid = (int)std::min<size_t>((n16 + 256 * 4 - 1) / (256 * 4), 256 * 16);
+    MTC_REQUIRE(n16 / 256 < 0x7fffffffull, "mtc_copy16: at most 2^31 workgroups of 4 KiB");
+    const unsigned grid = (unsigned)((n16 + 255) / 256);
     hipLaunchKernelGGL(copy16_kernel, dim3(grid), dim3(256), 0, as_stream(stream), reinterpret_cast<const u32x4*>(src),
                        reinterpret_cast<u32x4*>(dst), n16);
     return check_launch("mtc_copy16");
