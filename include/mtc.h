@@ -384,6 +384,13 @@ int mtc_fused_backward_adam_enc_extra(const mtc_desc* d, const int32_t* col_ptr,
  * (default; environment MTC_FUSED_SLICED read once), 1 = never, 2 = whenever the shape allows; returns the previous
  * setting or -1.  Process-wide tuning / test knob, no counterpart in the reference. */
 int mtc_fused_set_sliced(int mode);
+/* Measurement aid, no counterpart in the reference and not on the product path: lower bound of a column-sliced form of
+ * the decoder-row gradient + Adam launch (pass 0: gather + gradient slice + partial row sums into scratch
+ * [D][A_t/256][2] floats; pass 1: gather again + update without projection).  tools/fused_ab.py times both passes next
+ * to the row kernel that is used.  Overwrites W_dec / the moments it is given (pass 1): hand it copies. */
+int mtc_diag_sliced_decoder_bound(const mtc_desc* d, const int32_t* col_ptr, const int32_t* csc_row,
+                                  const float* coef_csc, const void* g, void* W_dec, void* exp_avg,
+                                  void* exp_avg_sq, float* scratch, int32_t pass, void* stream);
 /* projection only (the reference method called on its own, sae.py:155-163) */
 int mtc_unitnorm_project(const mtc_desc* d, void* W_dec, void* grad, void* stream);
 
@@ -472,6 +479,11 @@ int mtc_aux_row_candidates(const mtc_desc* d, const void* acts, const int32_t* d
                            void* stream);
 int mtc_aux_count_at(const mtc_desc* d, const void* acts, const int32_t* dead_idx, const int32_t* n_dead_dev,
                      const uint32_t* row_tau_bits, int32_t* row_gt, int32_t* row_eq, void* stream);
+/* ... with the ties counted per prefix group (row_eq_groups [B][G], groups = d->prefix in local coordinates): what a
+ * feature-sharded caller all-gathers to grant a row's ties in ascending GLOBAL feature order (group, shard, local
+ * feature), so that the aux selection does not depend on the number of shards either. */
+int mtc_aux_count_at_groups(const mtc_desc* d, const void* acts, const int32_t* dead_idx, const int32_t* n_dead_dev,
+                            const uint32_t* row_tau_bits, int32_t* row_gt, int32_t* row_eq_groups, void* stream);
 
 /* a15 helpers: CSR <-> dense [B][D] in the model dtype (encode returns dense, decode takes it) */
 int mtc_densify(const mtc_desc* d, const int32_t* row_ptr, const int32_t* col_idx, const void* vals,

@@ -87,6 +87,7 @@ PROTOTYPES = {
     "mtc_fused_backward_adam_dec_extra": (C.c_int, [DP, P, P, P, P, P, P, P, P, P, HP, P, C.c_float, P, P, C.c_int32, P]),
     "mtc_fused_backward_adam_enc_extra": (C.c_int, [DP, P, P, P, P, P, P, P, P, P, P, P, P, HP, P, P, P, C.c_int32, P]),
     "mtc_fused_set_sliced": (C.c_int, [C.c_int]),
+    "mtc_diag_sliced_decoder_bound": (C.c_int, [DP, P, P, P, P, P, P, P, P, C.c_int32, P]),
     "mtc_comm_unique_id": (C.c_int, [P]),
     "mtc_comm_init": (C.c_int, [C.POINTER(P), C.c_int32, C.c_int32, P]),
     "mtc_comm_destroy": (C.c_int, [P]),
@@ -110,6 +111,7 @@ PROTOTYPES = {
     "mtc_aux_mask": (C.c_int, [C.c_int32, C.c_uint64, P, P, P]),
     "mtc_aux_row_candidates": (C.c_int, [DP, P, P, P, P, P, C.c_int32, P, P]),
     "mtc_aux_count_at": (C.c_int, [DP, P, P, P, P, P, P, P]),
+    "mtc_aux_count_at_groups": (C.c_int, [DP, P, P, P, P, P, P, P]),
     "mtc_densify": (C.c_int, [DP, P, P, P, C.c_int32, P, P]),
     "mtc_copy16": (C.c_int, [P, P, C.c_size_t, P]),
     "mtc_gather_row_pairs": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, P, P, P, P, P, P, P]),

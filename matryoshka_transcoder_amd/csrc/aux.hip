@@ -583,6 +583,48 @@ __global__ __launch_bounds__(256) void aux_count_at_kernel(const void* __restric
     if (lane == 0) { row_gt[row] = (int32_t)gt; row_eq[row] = (int32_t)eq; }
 }
 
+// the same with the ties counted per prefix group (row_eq [B][G]): a feature-sharded caller grants a row's ties in
+// ascending GLOBAL feature order = (group, shard, local feature), for which it needs every shard's count per group
+struct AuxGroupBounds { int G; int prefix[MTC_MAX_PREFIX]; };
+template <int DT>
+__global__ __launch_bounds__(256) void aux_count_at_groups_kernel(const void* __restrict__ acts, int B, int D,
+                                                                  const int32_t* __restrict__ dead_idx,
+                                                                  const int32_t* __restrict__ n_dead_p,
+                                                                  const uint32_t* __restrict__ row_tau, AuxGroupBounds gb,
+                                                                  int32_t* __restrict__ row_gt, int32_t* __restrict__ row_eq) {
+    const int lane = threadIdx.x & 63;
+    const int row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (row >= B) return;
+    const int n_dead = *n_dead_p;
+    const uint32_t tau = row_tau[row];
+    const size_t base = (size_t)row * D;
+    uint32_t gt = 0;
+    uint32_t eq[MTC_MAX_PREFIX];
+#pragma unroll
+    for (int q = 0; q < MTC_MAX_PREFIX; ++q) eq[q] = 0;
+    for (int i = lane; i < n_dead; i += 64) {
+        const int col = dead_idx[i];
+        const uint32_t k = key_of<DT>(acts, base + col);
+        const bool ok = k != 0 && k <= 0x7f800000u;
+        gt += (ok && k > tau) ? 1u : 0u;
+        if (ok && tau != 0 && k == tau) {
+            int g = 0;
+            for (int q = 0; q + 1 < gb.G; ++q) g += col >= gb.prefix[q] ? 1 : 0;
+#pragma unroll
+            for (int q = 0; q < MTC_MAX_PREFIX; ++q) eq[q] += (g == q) ? 1u : 0u;
+        }
+    }
+    gt = wave_sum_u32(gt);
+    for (int q = 0; q < gb.G; ++q) {
+        uint32_t e = 0;
+#pragma unroll
+        for (int z = 0; z < MTC_MAX_PREFIX; ++z) e = z == q ? eq[z] : e;
+        e = wave_sum_u32(e);
+        if (lane == 0) row_eq[(size_t)row * gb.G + q] = (int32_t)e;
+    }
+    if (lane == 0) row_gt[row] = (int32_t)gt;
+}
+
 // d[i] = 0 where the aux activation is not selected (ReLU / TopK mask of the aux branch's backward)
 template <int DT>
 __global__ __launch_bounds__(256) void aux_mask_kernel(size_t n, const void* __restrict__ acts_aux, void* __restrict__ dvals) {
@@ -878,6 +920,23 @@ extern "C" int mtc_aux_count_at(const mtc_desc* d, const void* acts, const int32
         hipLaunchKernelGGL(aux_count_at_kernel<MTC_F32>, grid, block, 0, as_stream(stream), acts, d->B, d->D, dead_idx, n_dead_dev,
                            row_tau_bits, row_gt, row_eq);
     return check_launch("mtc_aux_count_at");
+}
+
+extern "C" int mtc_aux_count_at_groups(const mtc_desc* d, const void* acts, const int32_t* dead_idx, const int32_t* n_dead_dev,
+                                       const uint32_t* row_tau_bits, int32_t* row_gt, int32_t* row_eq_groups, void* stream) {
+    if (check_desc(d, "mtc_aux_count_at_groups")) return -1;
+    MTC_REQUIRE(acts && dead_idx && n_dead_dev && row_tau_bits && row_gt && row_eq_groups, "mtc_aux_count_at_groups: null pointer");
+    AuxGroupBounds gb;
+    gb.G = d->G;
+    for (int i = 0; i < MTC_MAX_PREFIX; ++i) gb.prefix[i] = i < d->G ? d->prefix[i] : 0x7fffffff;
+    const dim3 grid((d->B + 3) / 4), block(256);
+    if (d->dtype == MTC_BF16)
+        hipLaunchKernelGGL(aux_count_at_groups_kernel<MTC_BF16>, grid, block, 0, as_stream(stream), acts, d->B, d->D, dead_idx,
+                           n_dead_dev, row_tau_bits, gb, row_gt, row_eq_groups);
+    else
+        hipLaunchKernelGGL(aux_count_at_groups_kernel<MTC_F32>, grid, block, 0, as_stream(stream), acts, d->B, d->D, dead_idx,
+                           n_dead_dev, row_tau_bits, gb, row_gt, row_eq_groups);
+    return check_launch("mtc_aux_count_at_groups");
 }
 
 extern "C" int mtc_aux_residual(const mtc_desc* d, const void* x_hat_aux, const void* x_target, const void* x_hat,

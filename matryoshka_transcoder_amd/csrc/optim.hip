@@ -294,13 +294,17 @@ __global__ __launch_bounds__(256, (DT == MTC_BF16 ? (NC <= 5 ? MTC_FUSED_WAVES :
 #ifndef MTC_SLICED_U
 #define MTC_SLICED_U 2
 #endif
-template <int DT, int LPF, int EXTRA>
+//   PASS_A = 1 (measurement only, mtc_diag_sliced_decoder_bound): what a column-sliced DECODER-row kernel would have
+//   to run before its update pass -- gather, gradient slice, and the slice's share of the two row-wide sums the unit-norm
+//   projection needs (|w|^2 and grad . w), written to scratch [D][slices][2]; no moments, nothing updated.
+template <int DT, int LPF, int EXTRA, int PASS_A = 0>
 __global__ __launch_bounds__(256, 8) void fused_enc_sliced_kernel(
     int D, int A, int units_per_slice, int total_units, const int32_t* __restrict__ col_ptr,
     const int32_t* __restrict__ csc_row, const float* __restrict__ coef, const void* __restrict__ src,
     const float* __restrict__ scale_p, void* __restrict__ W, void* __restrict__ m, void* __restrict__ v,
     void* __restrict__ bias, void* __restrict__ m_b, void* __restrict__ v_b, AdamK k,
-    const int32_t* __restrict__ extra_row, const void* __restrict__ extra, const void* __restrict__ extra_bias) {
+    const int32_t* __restrict__ extra_row, const void* __restrict__ extra, const void* __restrict__ extra_bias,
+    float* __restrict__ pass_a_out = nullptr) {
     typedef DType<DT> D_;
     typedef typename D_::T T;
     constexpr int F = 64 / LPF;                    // features per wave
@@ -380,6 +384,21 @@ __global__ __launch_bounds__(256, 8) void fused_enc_sliced_kernel(
             issue(i + 2 * U, dr[0], c[0]);
             if (i + U < cnt) consume(dr[1], c[1]);
         }
+    }
+    if constexpr (PASS_A != 0) {
+        const Raw<DT> pwa = load_raw_nt<DT>(W, jv ? off : 0);
+        float wv[8], ss = 0.f, dt = 0.f;
+        unpack(pwa, wv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { ss = fmaf(wv[e], wv[e], ss); dt = fmaf(D_::rnd(acc[e]), wv[e], dt); }
+#pragma unroll
+        for (int o = 1; o < LPF; o <<= 1) { ss += __shfl_xor(ss, o, 64); dt += __shfl_xor(dt, o, 64); }
+        if (jv && sub == 0) {
+            const int n_slices = A / (LPF * 8);
+            pass_a_out[((size_t)j * n_slices + slice) * 2] = ss;
+            pass_a_out[((size_t)j * n_slices + slice) * 2 + 1] = dt;
+        }
+        return;
     }
     if (!jv) return;
     // parameter / moment pieces AFTER the gather loop: a wave's memory reads return in order, so requesting them first
@@ -487,6 +506,37 @@ extern "C" int mtc_unitnorm_project(const mtc_desc* d, void* W_dec, void* grad, 
     if (d->dtype == MTC_BF16) LAUNCH_ROWS(MTC_BF16, 0);
     else LAUNCH_ROWS(MTC_F32, 0);
     return check_launch("mtc_unitnorm_project");
+}
+
+// Measurement aid (no counterpart in the reference, not on the product path): lower bound of a column-sliced form of the
+// DECODER-row gradient + Adam launch.  The unit-norm projection needs two row-wide sums before any element of the row can
+// be updated, so a sliced form has two passes over the slices: pass 0 = gather + gradient slice + partial sums (this
+// kernel with PASS_A: no moments, nothing written but 8 bytes per feature and slice; the d a_bj dot products a real
+// pass A also owes are NOT included), pass 1 = gather again + update = the encoder-row sliced kernel run on the decoder's
+// operands (no projection arithmetic).  tools/fused_ab.py times both next to the row kernel.
+extern "C" int mtc_diag_sliced_decoder_bound(const mtc_desc* d, const int32_t* col_ptr, const int32_t* csc_row,
+                                             const float* coef_csc, const void* g, void* W_dec, void* exp_avg, void* exp_avg_sq,
+                                             float* scratch, int32_t pass, void* stream) {
+    if (check_desc(d, "mtc_diag_sliced_decoder_bound")) return -1;
+    MTC_REQUIRE(col_ptr && csc_row && coef_csc && g && W_dec && exp_avg && exp_avg_sq && scratch, "mtc_diag_sliced_decoder_bound: null pointer");
+    MTC_REQUIRE(d->dtype == MTC_BF16 && d->A_t % 256 == 0, "mtc_diag_sliced_decoder_bound: bf16, A_t a multiple of 256");
+    const int A = d->A_t, lpf = 32;
+    const int feats_per_block = 4 * (64 / lpf);
+    const int units_per_slice = (d->D + feats_per_block - 1) / feats_per_block;
+    const int total_units = units_per_slice * (A / (lpf * 8));
+    const dim3 grid(8 * ((total_units + 7) / 8)), block(256);
+    mtc_adam_hyper h = {3e-4, 0.9, 0.99, 1e-8, 1, 0};
+    const AdamK k = make_adam(&h);
+    hipStream_t s = as_stream(stream);
+    if (pass == 0)
+        hipLaunchKernelGGL((fused_enc_sliced_kernel<MTC_BF16, 32, 0, 1>), grid, block, 0, s, d->D, A, units_per_slice, total_units, col_ptr,
+                           csc_row, coef_csc, g, (const float*)nullptr, W_dec, exp_avg, exp_avg_sq, (void*)nullptr, (void*)nullptr,
+                           (void*)nullptr, k, (const int32_t*)nullptr, (const void*)nullptr, (const void*)nullptr, scratch);
+    else
+        hipLaunchKernelGGL((fused_enc_sliced_kernel<MTC_BF16, 32, 0, 0>), grid, block, 0, s, d->D, A, units_per_slice, total_units, col_ptr,
+                           csc_row, coef_csc, g, (const float*)nullptr, W_dec, exp_avg, exp_avg_sq, (void*)nullptr, (void*)nullptr,
+                           (void*)nullptr, k, (const int32_t*)nullptr, (const void*)nullptr, (const void*)nullptr, (float*)nullptr);
+    return check_launch("mtc_diag_sliced_decoder_bound");
 }
 
 extern "C" int mtc_fused_set_sliced(int mode) {
@@ -605,8 +655,8 @@ extern "C" int mtc_fused_backward_adam_enc_extra(const mtc_desc* d, const int32_
         const int total_units = units_per_slice * (A / (lpf * 8));
         const dim3 grid(8 * ((total_units + 7) / 8)), block(256);
 #define LAUNCH_SLICED(LPFV, EX)                                                                                                  \
-        hipLaunchKernelGGL((fused_enc_sliced_kernel<MTC_BF16, LPFV, EX>), grid, block, 0, s, d->D, A, units_per_slice, total_units, \
-                           col_ptr, csc_row, d_vals, src, scale, W, m, v, bias, m_b, v_b, k, extra_row, extra, extra_bias)
+        hipLaunchKernelGGL((fused_enc_sliced_kernel<MTC_BF16, LPFV, EX, 0>), grid, block, 0, s, d->D, A, units_per_slice, total_units, \
+                           col_ptr, csc_row, d_vals, src, scale, W, m, v, bias, m_b, v_b, k, extra_row, extra, extra_bias, (float*)nullptr)
         if (extra_row) { if (lpf == 32) LAUNCH_SLICED(32, 1); else if (lpf == 16) LAUNCH_SLICED(16, 1); else LAUNCH_SLICED(8, 1); }
         else { if (lpf == 32) LAUNCH_SLICED(32, 0); else if (lpf == 16) LAUNCH_SLICED(16, 0); else LAUNCH_SLICED(8, 0); }
 #undef LAUNCH_SLICED

@@ -377,8 +377,8 @@ class ShardedMatryoshkaTranscoder(MatryoshkaTranscoder):
         + one fp32 all-reduce, and the three backward products are local GEMMs whose rows ride into the fused gradient
         kernels.  The per-row top-k_aux over ALL dead features: local top-k_aux values per row (mtc_aux_select +
         mtc_aux_row_candidates) -> all-gather -> mtc_aux_select on the gathered [B, world*k] matrix = global threshold
-        and tie quota per row -> local counts at the threshold (mtc_aux_count_at), all-gathered so that ties are granted
-        in (rank, feature) order -> mtc_aux_dense_fill.  Three small collectives + the all-reduce."""
+        and tie quota per row -> local counts at the threshold per prefix group (mtc_aux_count_at_groups), all-gathered so
+        that ties are granted in ascending global feature order (group, rank, feature) -> mtc_aux_dense_fill.  Three small collectives + the all-reduce."""
         cfg, comm = self.config, self.comm
         if cfg.get("aux_mode", "gemm") != "gemm":
             return self._run_aux_sparse(hp, d, acts, sel, W_dec, x_target, x_hat, g, need_grad, l1_term)
@@ -402,12 +402,18 @@ class ShardedMatryoshkaTranscoder(MatryoshkaTranscoder):
         g_cnt, g_tau, g_quota = (torch.empty(B, **i32) for _ in range(3))
         check(lib.mtc_aux_select(C.byref(d2), _p(allc), _p(idx2), _p(n2), k_aux, _p(g_cnt), _p(g_tau), _p(g_quota), s),
               "mtc_aux_select")
-        gt_loc, eq_loc = torch.empty(B, **i32), torch.empty(B, **i32)
-        check(lib.mtc_aux_count_at(C.byref(d), _p(acts), _p(dead_idx), _p(n_dead), _p(g_tau), _p(gt_loc), _p(eq_loc), s),
-              "mtc_aux_count_at")
-        all_eq = comm.all_gather(eq_loc)                                         # [world, B]
-        before = all_eq[:comm.rank].sum(0, dtype=torch.int32) if comm.rank > 0 else torch.zeros(B, **i32)
-        take = torch.minimum((g_quota - before).clamp_min(0), eq_loc).contiguous()
+        G = d.G
+        gt_loc, eq_loc = torch.empty(B, **i32), torch.empty(B, G, **i32)
+        check(lib.mtc_aux_count_at_groups(C.byref(d), _p(acts), _p(dead_idx), _p(n_dead), _p(g_tau), _p(gt_loc), _p(eq_loc), s),
+              "mtc_aux_count_at_groups")
+        all_eq = comm.all_gather(eq_loc)                                         # [world, B, G]
+        # a row's ties in ascending GLOBAL feature order = (group, rank, local feature): what precedes this rank's ties
+        # of group g = all ties of earlier groups + those of earlier ranks in g (the single-GPU order, whatever the world)
+        grp_tot = all_eq.sum(0, dtype=torch.int32)
+        before = torch.cumsum(grp_tot, 1, dtype=torch.int32) - grp_tot
+        if comm.rank > 0:
+            before = before + all_eq[:comm.rank].sum(0, dtype=torch.int32)
+        take = torch.minimum((g_quota.unsqueeze(1) - before).clamp_min(0), eq_loc).sum(1, dtype=torch.int32).contiguous()
         # local part of acts_aux over the local dead set (bucketed width, zero padding), local product on libmtc's own
         # MFMA tiles with an fp32 result, fp32 all-reduce.  The local count sizes local launches only (the collectives
         # have fixed shapes), so it is the one read-back of this branch -- by now long on the host (copy issued above)

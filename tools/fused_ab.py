@@ -53,10 +53,24 @@ def main():
         lib.mtc_fused_backward_adam_dec_extra = timed(f"dec[{tag}]", real_dec)
         lib.mtc_fused_backward_adam_enc_extra = timed(f"enc[{tag}]", real_enc)
         hp.fused_backward_adam(d, sel, g, None, xs, None, W_dec, (m, v), W_encT, (m2, v2), b_enc, (mb, vb), h, h, h)
+    # lower bound of a column-sliced DECODER-row launch (two passes over the slices, see mtc_diag_sliced_decoder_bound)
+    import ctypes as C
+    from matryoshka_transcoder_amd.engine import _p, _stream
+    Wc, mc, vc = W_dec.clone(), m.clone(), v.clone()
+    coef_csc = sel.vals[sel.csc_pos.long()].float().contiguous()
+    scratch = torch.empty(D * (A // 256) * 2, dtype=torch.float32, device=dev)
+    for ps, tag in ((0, "dec sliced bound: pass A (gather + partial sums)"), (1, "dec sliced bound: pass B (gather + update)")) * args.reps:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = lib.mtc_diag_sliced_decoder_bound(C.byref(d), _p(sel.col_ptr), _p(sel.csc_row), _p(coef_csc), _p(g), _p(Wc), _p(mc),
+                                               _p(vc), _p(scratch), ps, _stream())
+        e1.record()
+        assert rc == 0
+        evs.setdefault(tag, []).append((e0, e1))
     torch.cuda.synchronize()
     for name, lst in sorted(evs.items()):
         t = sorted(a.elapsed_time(b) for a, b in lst[2:])
-        print(f"{name:14s} median {t[len(t) // 2]:.4f} ms  min {t[0]:.4f} ms  ({len(t)} launches)", flush=True)
+        print(f"{name:52s} median {t[len(t) // 2]:.4f} ms  min {t[0]:.4f} ms  ({len(t)} launches)", flush=True)
 
 
 if __name__ == "__main__":
