@@ -413,7 +413,7 @@ def main():
         }
         calib = hbm_calibration(device)
         # stage -> (launches per step, kernel name in the committed PMC summary) for the stages priced below
-        launches = {"encode": (1, "mtc::encode_bf16_mfma256p_kernel<false>"), "decode": (1, "mtc::decode_fwd_kernel<1, 5>"),
+        launches = {"encode": (1, "mtc::encode_bf16_mfma256p_kernel<false, true>"), "decode": (1, "mtc::decode_fwd_kernel<1, 5>"),
                     "fused_backward_adam": (2, "mtc::fused_grad_adam_kernel<1, 1, 5, 1, 1, 0>")}     # (+ fused_enc_sliced_kernel)
         kernels = {}
         for n, t_ms in st.items():
@@ -450,7 +450,9 @@ def main():
         if args.workload == "gemma2-2b" and args.dtype == "bf16" and not args.unit_norm and pmc_files:
             with open(pmc_files[-1]) as f:
                 pmc = json.load(f)["kernels"]
-            traffic = pmc.get(launches.get(dom, (None, ""))[1], {}).get("hbm_bytes_per_launch")
+            want = launches.get(dom, (None, ""))[1]
+            hit = pmc.get(want) or next((v for k2, v in pmc.items() if want and k2.split("<")[0] == want.split("<")[0]), {})
+            traffic = hit.get("hbm_bytes_per_launch")
             traffic_src = os.path.relpath(pmc_files[-1], ROOT)
         result["roofline"] = {"kernel": launches.get(dom, (None, dom))[1] or dom, "stage": dom,
                               **{k2: kernels[dom][k2] for k2 in ("bound", "achieved", "peak", "unit", "frac")},

@@ -73,7 +73,11 @@ if os.path.exists("gpurun_out/pmc_enc/e_counter_collection.csv"):
                           "--reps 10 (config #2 operands, random data, back-to-back launches) and rocprofv3 --kernel-trace --stats "
                           "of the same program for the duration",
                "kernels": enc, "yardsticks": extra}, open(f"profiles/{tag}_encode_pmc.json", "w"), indent=1)
-for src, dst in ((f"gpurun_out/bench_aux_{tag}.json", f"profiles/{tag}_bench_aux_active.json"),
+for src, dst in ((f"gpurun_out/bench_sharded_{tag}.json", f"profiles/{tag}_bench_sharded_world1.json"),
+                 (f"gpurun_out/bench_sharded_lib_{tag}.json", f"profiles/{tag}_bench_sharded_world1_libmtc.json"),
+                 (f"gpurun_out/bench_sharded_x_{tag}.json", f"profiles/{tag}_bench_sharded_world1_with_self_exchanges.json"),
+                 (f"gpurun_out/hostcost_{tag}.txt", f"profiles/{tag}_hostcost.txt"),
+                 (f"gpurun_out/bench_aux_{tag}.json", f"profiles/{tag}_bench_aux_active.json"),
                  (f"gpurun_out/fused_ab_{tag}.txt", f"profiles/{tag}_fused_ab.txt"),
                  (f"gpurun_out/pmc_fused_{tag}.txt", f"profiles/{tag}_fused_pmc.txt")):
     if os.path.exists(src):
@@ -85,8 +89,10 @@ B, A, D, K_TOP, S_ = 4096, 2304, 36864, 96, 2
 NNZ = K_TOP * B
 HBM_PEAK, MFMA_PEAK = 8.0e12, 2.5e15
 work = {   # kernel-name prefix -> (bound, algorithmic work, compulsory bytes or None, note)
-    "mtc::encode_bf16_mfma256p_kernel": ("mfma", 2.0 * B * A * D, B * A * S_ + D * A * S_ + B * D * S_, "2 B A D FLOP; operands once + acts written"),
-    "mtc::select_candidates_kernel": ("hbm", B * D * S_ + NNZ * 8, B * D * S_, "one read of acts + candidates out"),
+    "mtc::encode_bf16_mfma256p_kernel": ("mfma", 2.0 * B * A * D, B * A * S_ + D * A * S_ + B * D * S_ + B * D // 128,
+                                         "2 B A D FLOP; operands once + acts and candidate marks written"),
+    "mtc::select_candidates_kernel": ("latency", 0, 0, "reads only the 32-byte granules of acts the encoder's epilogue flagged (~8 %; "
+                                      "the first pass over the B D activations happens there); see pmc_fabric_bytes"),
     "mtc::decode_fwd_kernel": ("hbm", NNZ * (A * S_ + 8) + 2 * B * A * S_, D * A * S_ + 3 * B * A * S_ + NNZ * 6,
                                "gather of nnz decoder rows + target in / x_hat, g out"),
     "mtc::fused_grad_adam_kernel": ("hbm", 6 * D * A * S_ + NNZ * A * S_ + B * A * S_, 6 * D * A * S_ + B * A * S_ + NNZ * 12,
@@ -115,8 +121,10 @@ for prefix, (bound, alg, comp, note) in work.items():
     elif bound == "hbm":
         row.update(algorithmic_bytes=int(alg), achieved_TBps=round(alg / per_step_us / 1e6, 2), frac_of_peak=round(alg / (per_step_us * 1e-6) / HBM_PEAK, 3),
                    compulsory_bytes=int(comp), frac_compulsory=round(comp / (per_step_us * 1e-6) / HBM_PEAK, 3))
-    if traffic and comp:
-        row.update(pmc_fabric_bytes=int(traffic), traffic_over_compulsory=round(traffic / comp, 2))
+    if traffic:
+        row.update(pmc_fabric_bytes=int(traffic))
+        if comp:
+            row.update(traffic_over_compulsory=round(traffic / comp, 2))
     rows.append(row)
 json.dump({"workload": "gemma2-2b bf16 (config #2): B 4096, A 2304, D 36864, k 96", "peaks": {"hbm_Bps": HBM_PEAK, "mfma_bf16_FLOPs": MFMA_PEAK},
            "sources": [f"profiles/{tag}_kernel_stats.csv (rocprofv3 --kernel-trace --stats)", f"profiles/{tag}_pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE)"],

@@ -19,12 +19,21 @@ timeout -s KILL 120 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_VALU_MFMA_
 timeout -s KILL 120 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_enc -o e -- python3 tools/encode_only.py --reps 10 > gpurun_out/prof_enc.log 2>&1 || exit 1
 timeout -k 10 120 python -u tools/encode_only.py --blas > gpurun_out/enc_random.json 2> gpurun_out/enc_random.err || exit 1
 timeout -k 10 120 python -u tools/encode_only.py --zeros > gpurun_out/enc_zeros.json 2> gpurun_out/enc_zeros.err || exit 1
-timeout -k 10 120 python -u tools/encode_stamps.py > gpurun_out/enc_stamps.json 2> gpurun_out/enc_stamps.err || exit 1
+# in-kernel clock / per-wave cycle stamps: needs the diagnostic build (tools/encode_stamps.sh; kept out of the push set by
+# .gpurunignore unless a measurement pass wants it)
+if [ -f matryoshka_transcoder_amd/libmtc_diag.so ]; then
+  timeout -k 10 120 python -u tools/encode_stamps.py > gpurun_out/enc_stamps.json 2> gpurun_out/enc_stamps.err || exit 1
+fi
 timeout -k 10 900 python -u tools/sweep.py > gpurun_out/sweep.log 2>&1 || { tail -5 gpurun_out/sweep.log; exit 1; }
 # the step with the auxiliary loss active (its products on mtc_gemm_nt), and the fused gradient + Adam launches A/B
 timeout -k 10 300 python -u bench.py --no-cpu-baseline --aux-active --steps 30 --warmup 3 > gpurun_out/bench_aux_$TAG.json 2> gpurun_out/bench_aux_$TAG.err || exit 1
 timeout -k 10 200 python -u tools/fused_ab.py > gpurun_out/fused_ab_$TAG.txt 2>&1 || exit 1
 bash tools/pmc_fused.sh > gpurun_out/pmc_fused_$TAG.txt 2>&1 || exit 1
+# the feature-sharded classes over RCCL with a one-rank group (fixed overhead of the sharded step), host issue cost
+timeout -k 10 300 python -u bench.py --no-cpu-baseline --sharded > gpurun_out/bench_sharded_$TAG.json 2> gpurun_out/bench_sharded_$TAG.err || exit 1
+timeout -k 10 300 python -u bench.py --no-cpu-baseline --sharded --comm libmtc > gpurun_out/bench_sharded_lib_$TAG.json 2> gpurun_out/bench_sharded_lib_$TAG.err || exit 1
+timeout -k 10 300 python -u bench.py --no-cpu-baseline --sharded --world1-exchanges > gpurun_out/bench_sharded_x_$TAG.json 2> gpurun_out/bench_sharded_x_$TAG.err || exit 1
+timeout -k 10 300 python -u tools/hostcost.py --dist > gpurun_out/hostcost_$TAG.txt 2>&1 || exit 1
 python3 - <<PY
 import json
 r = json.load(open("gpurun_out/bench_$TAG.json"))

@@ -92,7 +92,9 @@ def copy_calibration():
     del src, dst
     torch.cuda.empty_cache()
     torch.cuda.reset_peak_memory_stats()
-    return {"bytes_each_way": n, "ms": ms, "read_plus_write_GBps": 2 * n / ms / 1e6}
+    own = bench.hbm_calibration("cuda:0", gib=2.0)
+    return {"bytes_each_way": n, "torch_copy_ms": ms, "torch_copy_read_plus_write_GBps": 2 * n / ms / 1e6,
+            "mtc_copy16_ms": own["ms"], "mtc_copy16_read_plus_write_GBps": own["GBps_read_plus_write"]}
 
 
 def main():
