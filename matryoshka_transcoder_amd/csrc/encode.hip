@@ -133,6 +133,9 @@ __device__ __forceinline__ void glds16_aux(const void* gsrc, void* lds_dst) {
 #ifndef MTC_ENC_X_AUX
 #define MTC_ENC_X_AUX 0
 #endif
+#ifndef MTC_ENC_P0_ORDER
+#define MTC_ENC_P0_ORDER 0               // experiment: 1 = phase 0 issues its W staging before its 12 LDS reads, 2 = between the k-halves
+#endif
 
 // EPI 0: the encoder (round, + bias, round, ReLU / threshold; lda = ldb = K, ldc = N).  EPI 1 / 2: plain C = A . Bt^T
 // (mtc_gemm_nt: the auxiliary branch's products) rounded once to bf16 / kept in fp32, with row strides lda / ldb / ldc
@@ -395,6 +398,28 @@ constexpr int HALF_BYTES = 128 * 128;          // 16 KiB: 128 rows x 64 bf16
 // 16-MFMA cluster between its two barriers.
 template <int I0, int J0>
 __device__ __forceinline__ void mfma_quadrant(bf16x8 (&wf)[2][4], bf16x8 (&xf)[2][2], f32x4 (&acc)[8][4]) {
+#ifdef MTC_ENC_SPLIT_WAIT
+    // fragments are pinned k-half by k-half: the MFMAs of the first half start when ITS reads have landed (counted lgkmcnt),
+    // the second half's reads are still in flight underneath them
+#ifndef MTC_ABLATE_NOPRIO
+    __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(wf[ks][i]));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(xf[ks][j]));
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[I0 + i][J0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][i], xf[ks][j], acc[I0 + i][J0 + j], 0, 0, 0);
+    }
+#ifndef MTC_ABLATE_NOPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+#else
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -416,6 +441,7 @@ __device__ __forceinline__ void mfma_quadrant(bf16x8 (&wf)[2][4], bf16x8 (&xf)[2
 #endif
 #ifndef MTC_ABLATE_NOPRIO
     __builtin_amdgcn_s_setprio(0);
+#endif
 #endif
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -740,14 +766,29 @@ __global__ __launch_bounds__(512, 1) void encode_bf16_mfma256p_kernel(const u16*
         const int nb = (it + 1) & 1;
         const bool more = it + 1 < S, more2 = it + 2 < S;
         // ---------------- phase 0
+#if MTC_ENC_P0_ORDER == 1
+        if (more) stage_w(nb, 0, wk);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
+#if MTC_ENC_P0_ORDER == 2
+            if (ks == 1) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) stage_w(nb, 0, wk);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#endif
+#ifndef MTC_ABLATE_P0_XA
 #pragma unroll
             for (int j = 0; j < 2; ++j) xa[ks][j] = *reinterpret_cast<const bf16x8*>(cur + x_base + j * 16 * 128 + off[ks]);
+#endif
 #pragma unroll
             for (int i = 0; i < 4; ++i) wf[ks][i] = *reinterpret_cast<const bf16x8*>(cur + w_base + i * 16 * 128 + off[ks]);
         }
+#if !defined(MTC_ENC_STAGE_W_P1) && MTC_ENC_P0_ORDER == 0
         if (more) stage_w(nb, 0, wk);
+#endif
         PFENCE(0);
         mfma_quadrant<0, 0>(wf, xa, acc);
         PFENCE(1);
@@ -756,6 +797,9 @@ __global__ __launch_bounds__(512, 1) void encode_bf16_mfma256p_kernel(const u16*
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int j = 0; j < 2; ++j) xb[ks][j] = *reinterpret_cast<const bf16x8*>(cur + x_base + (2 + j) * 16 * 128 + off[ks]);
+#ifdef MTC_ENC_STAGE_W_P1
+        if (more) stage_w(nb, 0, wk);
+#endif
         if (more) { stage_w(nb, 1, wk); adv_w(); }
         PFENCE(2);
         mfma_quadrant<0, 2>(wf, xb, acc);
