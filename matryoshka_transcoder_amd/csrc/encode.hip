@@ -647,12 +647,17 @@ constexpr int P256_LDS = 2 * 4 * HALF_BYTES + 8 * STG_BYTES;     // 160 KiB: the
 // here, on the packed values the epilogue holds anyway (one packed max + a compare per 4 values, two cross-lane ORs and
 // one byte store per 16 rows x 128 features).  marks: uint8 [M][ceil(N / 128)] + one uint32 behind it (4-byte aligned)
 // that records the bound the marks were made for -- a select running with another bound ignores them.
-template <bool THR, bool MARK = false>
+//
+// EPI 1 / 2 (mtc_gemm_nt on large shapes: the auxiliary branch's products): plain C = A . Bt^T rounded once to bf16 / kept
+// in fp32, row strides lda / ldb / ldc, optional row gather on A (a_rows) -- the same tile walk, staging and schedule.
+template <bool THR, bool MARK = false, int EPI = 0>
 __global__ __launch_bounds__(512, 1) void encode_bf16_mfma256p_kernel(const u16* __restrict__ X, const u16* __restrict__ Wt,
                                                                       const u16* __restrict__ bias, u16* __restrict__ acts,
                                                                       int M, int N, int K, int mt, int nt, const void* __restrict__ thr,
                                                                       const uint32_t* __restrict__ carry = nullptr,
-                                                                      unsigned char* __restrict__ marks = nullptr) {
+                                                                      unsigned char* __restrict__ marks = nullptr,
+                                                                      long long lda = 0, long long ldb = 0, long long ldc = 0,
+                                                                      const int32_t* __restrict__ a_rows = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     uint32_t g16 = 0x10000u;                                                     // "nothing is a candidate"
@@ -698,8 +703,9 @@ __global__ __launch_bounds__(512, 1) void encode_bf16_mfma256p_kernel(const u16*
         lid_to_tile(lid, mt, nt, tm, tn);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            wsrc[h][0] = Wt + (size_t)min(tn * B2N + h * 128 + prow0, N - 1) * K + pch0;     // clamp: tails read valid rows
-            wsrc[h][1] = Wt + (size_t)min(tn * B2N + h * 128 + prow1, N - 1) * K + pch1;
+            const long long ld = EPI == 0 ? (long long)K : ldb;
+            wsrc[h][0] = Wt + (size_t)min(tn * B2N + h * 128 + prow0, N - 1) * ld + pch0;    // clamp: tails read valid rows
+            wsrc[h][1] = Wt + (size_t)min(tn * B2N + h * 128 + prow1, N - 1) * ld + pch1;
         }
     };
     auto set_x = [&](int lid) {
@@ -707,8 +713,15 @@ __global__ __launch_bounds__(512, 1) void encode_bf16_mfma256p_kernel(const u16*
         lid_to_tile(lid, mt, nt, tm, tn);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            xsrc[h][0] = X + (size_t)min(tm * B2M + h * 128 + prow0, M - 1) * K + pch0;
-            xsrc[h][1] = X + (size_t)min(tm * B2M + h * 128 + prow1, M - 1) * K + pch1;
+            const long long ld = EPI == 0 ? (long long)K : lda;
+            int r0 = min(tm * B2M + h * 128 + prow0, M - 1), r1 = min(tm * B2M + h * 128 + prow1, M - 1);
+            if constexpr (EPI != 0) {
+                // (a plain load between the LDS-DMA requests: its wait drains them once per tile, which only makes the
+                // counted waits behind it stronger)
+                if (a_rows) { r0 = a_rows[r0]; r1 = a_rows[r1]; }
+            }
+            xsrc[h][0] = X + (size_t)r0 * ld + pch0;
+            xsrc[h][1] = X + (size_t)r1 * ld + pch1;
         }
     };
     auto stage_w = [&](int buf, int h, int kt) {
@@ -844,12 +857,28 @@ __global__ __launch_bounds__(512, 1) void encode_bf16_mfma256p_kernel(const u16*
         ++cm;
         const int fcol = tn * B2N + wr * 128;                                    // first feature of this wave's block
         const int brow = tm * B2M + wc * 64;                                     // first batch row of it
+        if constexpr (EPI == 2) {
+            // fp32 result straight from the accumulators: 16 bytes per lane, 64 contiguous bytes per four lanes
+            float* C32 = reinterpret_cast<float*>(acts);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int b = brow + j * 16 + fr;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int f = fcol + i * 16 + fq * 4;
+                    if (b < M && f < N) *reinterpret_cast<f32x4*>(C32 + (size_t)b * ldc + f) = acc[i][j];
+                    acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            continue;
+        }
         uint2 bb[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int f = fcol + i * 16 + fq * 4;
-            bb[i] = f < N ? *reinterpret_cast<const uint2*>(bias + f) : uint2{0u, 0u};   // N % 8 == 0 -> in bounds, aligned
+            bb[i] = (EPI == 0 && f < N) ? *reinterpret_cast<const uint2*>(bias + f) : uint2{0u, 0u};   // N % 8 == 0 -> in bounds, aligned
         }
+        const long long ldo = EPI == 0 ? (long long)N : ldc;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             // lane holds features i*16 + fq*4 + (0..3) of batch row j*16 + fr: 8 bytes into row fr of the staging block,
@@ -859,8 +888,12 @@ __global__ __launch_bounds__(512, 1) void encode_bf16_mfma256p_kernel(const u16*
             for (int i = 0; i < 8; ++i) {
                 const f32x4 v = acc[i][j];
                 uint2 o;
-                o.x = bias_relu_pack2<THR>(v[0], v[1], bf16_bits_to_f32(bb[i].x & 0xffffu), bf16_bits_to_f32(bb[i].x >> 16), fl);
-                o.y = bias_relu_pack2<THR>(v[2], v[3], bf16_bits_to_f32(bb[i].y & 0xffffu), bf16_bits_to_f32(bb[i].y >> 16), fl);
+                if constexpr (EPI == 0) {
+                    o.x = bias_relu_pack2<THR>(v[0], v[1], bf16_bits_to_f32(bb[i].x & 0xffffu), bf16_bits_to_f32(bb[i].x >> 16), fl);
+                    o.y = bias_relu_pack2<THR>(v[2], v[3], bf16_bits_to_f32(bb[i].y & 0xffffu), bf16_bits_to_f32(bb[i].y >> 16), fl);
+                } else {
+                    o.x = pack2_bf16(v[0], v[1]); o.y = pack2_bf16(v[2], v[3]);                    // one rounding
+                }
                 *reinterpret_cast<uint2*>(stg + fr * 256 + ((((i << 1) | (fq >> 1)) ^ fr) << 4) + ((fq & 1) << 3)) = o;
                 acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if constexpr (MARK) {
@@ -885,7 +918,7 @@ __global__ __launch_bounds__(512, 1) void encode_bf16_mfma256p_kernel(const u16*
                 const int R = (lane >> 4) + 4 * s, c = lane & 15;
                 const u32x4 val = *reinterpret_cast<const u32x4*>(stg + R * 256 + ((c ^ R) << 4));
                 const int b = brow + j * 16 + R, f = fcol + c * 8;
-                if (b < M && f < N) *reinterpret_cast<u32x4*>(acts + (size_t)b * N + f) = val;
+                if (b < M && f < N) *reinterpret_cast<u32x4*>(acts + (size_t)b * ldo + f) = val;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // reads done before the next round overwrites
         }
@@ -1007,7 +1040,7 @@ static void encode_options_once() {
     if (g_f32_generic < 0) g_f32_generic = getenv("MTC_ENCODE_F32_GENERIC") ? 1 : 0;
 }
 constexpr int MAX_DEV = 64;
-static bool g_attr_done[10][MAX_DEV];
+static bool g_attr_done[12][MAX_DEV];
 static int g_cus[MAX_DEV];
 static void lds_opt_in(int which, const void* fn, int lds) {
     int dev = 0;
@@ -1152,7 +1185,27 @@ extern "C" int mtc_gemm_nt(int32_t dtype, int32_t M, int32_t N, int32_t K, const
                          ((uintptr_t)A % 16) == 0 && ((uintptr_t)Bt % 16) == 0 && ((uintptr_t)C % 16) == 0;
     const int mt = (M + BM - 1) / BM, nt = (N + BN - 1) / BN;
     const int lds = 2 * 2 * TILE_BYTES;
-    if (dtype == MTC_BF16 && aligned && (K % BK) == 0) {
+    // large products run the persistent 256 x 256 kernel (measured at the auxiliary branch's shapes, 144 - 352 big tiles:
+    // 0.121 / 0.109 / 0.099 ms against 0.149 / 0.128 / 0.140 on the 128 x 128 tile, tools/aux_gemm_ab.py); MTC_ENCODE_TILE /
+    // mtc_encode_set_tile() force either form like they do for the encoder
+    const int big_tiles = ((M + B2M - 1) / B2M) * ((N + B2N - 1) / B2N);
+    const bool wide_ok = (N % 8) == 0 && (ldc % 8) == 0;                          // 16-byte bf16 stores of the epilogue
+    if (dtype == MTC_BF16 && aligned && (K % BK) == 0 && (out_f32 || wide_ok) && g_tile != 1 && g_tile != 3 &&
+        (g_tile == 2 || 2 * big_tiles >= cu_count())) {
+        const int mt2 = (M + B2M - 1) / B2M, nt2 = (N + B2N - 1) / B2N;
+        const int grid = min(mt2 * nt2, cu_count());
+        if (out_f32) {
+            lds_opt_in(8, reinterpret_cast<const void*>(encode_bf16_mfma256p_kernel<false, false, 2>), P256_LDS);
+            hipLaunchKernelGGL((encode_bf16_mfma256p_kernel<false, false, 2>), dim3(grid), dim3(512), P256_LDS, s, (const u16*)A,
+                               (const u16*)Bt, (const u16*)nullptr, (u16*)C, M, N, K, mt2, nt2, (const void*)nullptr,
+                               (const uint32_t*)nullptr, (unsigned char*)nullptr, (long long)lda, (long long)ldb, (long long)ldc, a_rows);
+        } else {
+            lds_opt_in(10, reinterpret_cast<const void*>(encode_bf16_mfma256p_kernel<false, false, 1>), P256_LDS);
+            hipLaunchKernelGGL((encode_bf16_mfma256p_kernel<false, false, 1>), dim3(grid), dim3(512), P256_LDS, s, (const u16*)A,
+                               (const u16*)Bt, (const u16*)nullptr, (u16*)C, M, N, K, mt2, nt2, (const void*)nullptr,
+                               (const uint32_t*)nullptr, (unsigned char*)nullptr, (long long)lda, (long long)ldb, (long long)ldc, a_rows);
+        }
+    } else if (dtype == MTC_BF16 && aligned && (K % BK) == 0) {
         if (out_f32) {
             lds_opt_in(5, reinterpret_cast<const void*>(encode_bf16_mfma_kernel<2>), lds);
             hipLaunchKernelGGL(encode_bf16_mfma_kernel<2>, dim3(mt * nt), dim3(256), lds, s, (const u16*)A, (const u16*)Bt,

@@ -66,6 +66,46 @@ def test_gemm_nt_against_fp32_contraction(dt, M, N, K, lda_pad, gather, gpu_lib)
             assert float((got == want).float().mean()) >= 0.99      # roundings flip only where the fp32 sums straddle a tie
 
 
+@pytest.mark.parametrize("M,N,K,lda_pad,ldc_pad,gather", [
+    (256, 256, 64, 0, 0, False),          # one 256 x 256 tile, one k-step
+    (700, 520, 448, 0, 0, False),         # ragged tiles on both sides, an odd number of k-steps
+    (300, 1096, 640, 64, 24, True),       # gathered A rows, row strides longer than the rows on A and C
+    (2816, 2304, 1024, 0, 0, False),      # 99 tiles, 16 k-steps
+    (5632, 2304, 4096, 0, 0, True),       # E_dec / E_enc at config #2 with 5 632 dead columns: the automatic route
+])
+def test_gemm_nt_persistent_tile_equals_small_tile(M, N, K, lda_pad, ldc_pad, gather, gpu_lib):
+    """Large bf16 products run the persistent 256 x 256 kernel (plain epilogue).  Same contraction order per output
+    (k ascending in 32-wide MFMA steps, fp32 accumulate, one rounding), so bf16 AND fp32 outputs must equal the
+    128 x 128 tile's bit for bit -- which test_gemm_nt_against_fp32_contraction pins to the fp32 contraction."""
+    g = torch.Generator("cpu").manual_seed(M + N + K)
+    rows_total = M + 29 if gather else M
+    lda, ldc = K + lda_pad, N + ldc_pad
+    A = torch.randn(rows_total, lda, generator=g).to(torch.bfloat16).to(DEV)
+    Bt = torch.randn(N, K, generator=g).to(torch.bfloat16).to(DEV)
+    ar = torch.randperm(rows_total, generator=g)[:M].to(torch.int32).to(DEV) if gather else None
+    hp = _hp(torch.bfloat16)
+    lib = hp.lib
+    for out_f32 in (False, True):
+        odt = torch.float32 if out_f32 else torch.bfloat16
+        outs = []
+        for tile in (1, 2):
+            prev = lib.mtc_encode_set_tile(tile)
+            try:
+                out = torch.full((M, ldc), -3.0, dtype=odt, device=DEV)
+                hp.gemm_nt(M, N, K, A, lda, Bt, K, out, ldc, a_rows=ar, out_f32=out_f32)
+                torch.cuda.synchronize()
+            finally:
+                lib.mtc_encode_set_tile(prev)
+            outs.append(out)
+        assert torch.equal(outs[0], outs[1]), (out_f32, float((outs[0].float() - outs[1].float()).abs().max()))
+        assert bool((outs[1][:, N:] == -3.0).all())                      # the padding of C's rows is not written
+        if M * N >= 5632 * 2304:                                          # the size the automatic choice sends to the big tile
+            out = torch.empty(M, ldc, dtype=odt, device=DEV)
+            hp.gemm_nt(M, N, K, A, lda, Bt, K, out, ldc, a_rows=ar, out_f32=out_f32)
+            torch.cuda.synchronize()
+            assert torch.equal(out[:, :N], outs[1][:, :N])
+
+
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
 def test_transpose_rows_mask_rowsum_scatter_add(dt, gpu_lib):
     g = torch.Generator("cpu").manual_seed(3)
