@@ -100,10 +100,12 @@ __global__ __launch_bounds__(256) void select_hist_kernel(const void* __restrict
 
 // one workgroup of 1024 threads: suffix scan over 4096 bins, pick the bin holding the k_rem-th largest
 __global__ __launch_bounds__(1024) void select_scan_kernel(const uint32_t* __restrict__ hist, int level, int last_level,
-                                                           mtc_select_state* st) {
+                                                           mtc_select_state* st, const uint32_t* __restrict__ pred = nullptr,
+                                                           uint32_t want = 0) {
     __shared__ uint32_t part[1024];
     __shared__ uint32_t found_bin, found_above;
     const int t = threadIdx.x;
+    if (pred && *pred != want) return;                 // uniform (carried-bound select: the window tail served this call)
     if (st->all_pos) return;                           // uniform: whole block leaves
     // thread t owns bins [4t, 4t+3]; "above" = higher bin index
     const uint32_t h0 = hist[4 * t], h1 = hist[4 * t + 1], h2 = hist[4 * t + 2], h3 = hist[4 * t + 3];
@@ -527,6 +529,7 @@ template <> __device__ __forceinline__ bool chunk_may_hold<MTC_F32>(const Raw<MT
 // than a wave's worth, 64 queued chunks are examined exactly, one per lane, and their candidates are written out in
 // order.  The exact test / ordered compaction therefore runs once per ~25 loads instead of once per load.
 constexpr int CAND_QCAP = 128;
+constexpr int CAND_WIN = 32;            // window of the bf16 fast path: bins 0 .. 30 = ulps above the bound, bin 31 = 31 or more
 // marks (optional; written by the encoder's epilogue, see encode_bf16_mfma256p_kernel<.., MARK>): uint8 [B][ceil(D / 128)],
 // bit i of a byte = "features [16 i, 16 i + 16) of that 128-feature block may hold an entry >= the bound", followed by
 // the bound they were made for.  When that bound is the one carried now, only the flagged 32-byte granules are read
@@ -536,17 +539,23 @@ template <int DT>
 __global__ __launch_bounds__(256) void select_candidates_kernel(const void* __restrict__ acts, int B, int D, int C,
                                                                 const uint32_t* __restrict__ carry, void* __restrict__ cand_vals,
                                                                 int32_t* __restrict__ cand_cols, uint32_t* __restrict__ cand_cnt,
-                                                                const unsigned char* __restrict__ marks) {
+                                                                const unsigned char* __restrict__ marks,
+                                                                unsigned short* __restrict__ row_win = nullptr) {
     typedef typename DType<DT>::T T;
     constexpr int U = DT == MTC_BF16 ? 8 : 4;
     __shared__ Raw<DT> q_raw[4][CAND_QCAP];
     __shared__ int q_chunk[4][CAND_QCAP];
+    __shared__ uint32_t s_win[4][CAND_WIN];
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
     const int row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + w);
     if (row >= B) return;
     const uint32_t guess = carry[0];
     if (guess == 0) return;
+    // bf16: the row's candidates counted by distance from the bound in bf16 ulps (see select_window_tail_kernel); the
+    // counters are private to the wave, whose LDS operations complete in order
+    const bool win = DT == MTC_BF16 && row_win != nullptr;
+    if (win && lane < CAND_WIN) s_win[w][lane] = 0;
     const size_t base = (size_t)row * D;
     T* vout = reinterpret_cast<T*>(cand_vals) + (size_t)row * C;
     int32_t* cout = cand_cols + (size_t)row * C;
@@ -592,6 +601,7 @@ __global__ __launch_bounds__(256) void select_candidates_kernel(const void* __re
 #pragma unroll
                     for (int q = 1; q < 8; ++q) val = i == q ? v[q] : val;
                     if (pos < (uint32_t)C) { DType<DT>::st(vout + pos, val); cout[pos] = c * 8 + i; }
+                    if (win) atomicAdd(&s_win[w][min((__float_as_uint(val) - guess) >> 16, (uint32_t)CAND_WIN - 1u)], 1u);
                     ++pos;
                     mm &= mm - 1;
                 }
@@ -679,6 +689,14 @@ __global__ __launch_bounds__(256) void select_candidates_kernel(const void* __re
     const float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (uint32_t ch = (al >> 3) + lane; ch < (uint32_t)(C >> 3); ch += 64) store8<DT>(vout, (size_t)ch * 8, z);
     if (lane == 0) cand_cnt[row] = out;
+    if (win) {
+        // INCLUSIVE prefix over the bins: row_win[row][b] = candidates of the row at most b ulps above the bound (bin 31:
+        // all of them), so the tail needs two entries per row once it knows tau's bin
+        uint32_t p = lane < CAND_WIN ? s_win[w][lane] : 0u;
+#pragma unroll
+        for (int o = 1; o < CAND_WIN; o <<= 1) { const uint32_t n = __shfl_up(p, o, 64); if (lane >= o) p += n; }
+        if (lane < CAND_WIN) row_win[(size_t)row * CAND_WIN + lane] = (unsigned short)min(p, 65535u);
+    }
 }
 
 // one workgroup, after the candidate pass: total / overflow from the per-row counts -> which path is valid
@@ -830,7 +848,9 @@ __global__ __launch_bounds__(1024) void select_tail_kernel(int B, mtc_select_sta
                                                            const uint32_t* __restrict__ row_sub, uint32_t* row_gt,
                                                            uint32_t* row_eq, int32_t* __restrict__ row_ptr,
                                                            uint32_t* __restrict__ tie_take, uint32_t* carry, void* threshold,
-                                                           float lr) {
+                                                           float lr, const uint32_t* __restrict__ pred = nullptr,
+                                                           uint32_t want = 0) {
+    if (pred && *pred != want) return;                 // uniform (the window tail served this call)
     if (with_finish) {
         select_finish_body(B, st, row_above, row_sub, nullptr, row_gt, row_eq);
         __threadfence_block();
@@ -838,6 +858,381 @@ __global__ __launch_bounds__(1024) void select_tail_kernel(int B, mtc_select_sta
     }
     select_offsets_body(B, row_gt, row_eq, nullptr, st, row_ptr, tie_take, carry);
     if (threshold && threadIdx.x == 0) threshold_ema_body<DT>(st, threshold, lr);     // thread 0 wrote st->nnz / min_sel_bits itself
+}
+
+// bf16 fast path of the carried-bound select: ONE workgroup turns the candidate pass's per-row window counts into the whole
+// answer.  A bf16 key has 16 bits and every candidate is >= the bound, so "key16 - bound16" is an EXACT histogram bin.
+// row_win [B][32] holds, per row, the inclusive prefix counts over those bins (bin 31 = "31 ulps or more": every candidate of
+// the row).  Their column sums S[b] are the global counts "at most b ulps above the bound": tot - S[b] entries lie above bin
+// b, so the scan from the top gives tau, the count above it and the tie quota (what select_hist / select_scan /
+// select_rowsub / the finish piece produce in four launches), and two entries per row give its (> tau, == tau) counts.  Then
+// CSR offsets with the tie quota in ascending flat index, the next bound and the threshold EMA (select_offsets_body /
+// threshold_ema_body restated on registers).  Valid when the bound held (enough candidates, no row overflow) AND tau lies
+// inside the window (the bound sits 8 ulps under the previous tau, so tau may rise 22 ulps in one step); otherwise
+// carry[1] = 0, the level histograms are zeroed and the full-size launches behind this one run instead (they leave at once
+// when carry[1] == 1).  Also initialises st (what mtc_select_init does).
+// A single workgroup pays ~2 us per dependent round trip to L2 and one CU moves ~one cache line per clock, so every global
+// value is requested once, in batches, with consecutive lanes on consecutive addresses: the column sums read row_win as a
+// flat array (16-byte piece u = i * 1024 + t: a thread always sees the same quarter of the bins), rows t, t + 1024, ... belong
+// to thread t for the per-row part (B <= 4096; REGS), whose four row segments are scanned side by side.  Larger batches
+// (REGS = false) loop over a contiguous row range per thread.
+__device__ __forceinline__ void block_excl_scan4_1024(const uint32_t (&v)[4], uint32_t (*sm)[4], uint32_t (&excl)[4],
+                                                      uint32_t (&total)[4]) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t inc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) inc[j] = v[j];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const uint32_t n = __shfl_up(inc[j], o, 64); if (lane >= o) inc[j] += n; }
+    if (lane == 63)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sm[w][j] = inc[j];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        uint32_t wbase = 0, tot = 0;
+        for (int i = 0; i < 16; ++i) { const uint32_t x = sm[i][j]; if (i < w) wbase += x; tot += x; }
+        excl[j] = wbase + inc[j] - v[j];
+        total[j] = tot;
+    }
+    __syncthreads();
+}
+
+template <int DT, bool REGS>
+__global__ __launch_bounds__(1024) void select_window_tail_kernel(int B, int C, uint32_t k_total, mtc_select_state* st,
+                                                                  uint32_t* carry, const uint32_t* __restrict__ cand_cnt,
+                                                                  const unsigned short* __restrict__ row_win,
+                                                                  uint32_t* __restrict__ hist, uint32_t* row_gt, uint32_t* row_eq,
+                                                                  int32_t* __restrict__ row_ptr, uint32_t* __restrict__ tie_take,
+                                                                  void* threshold, float lr) {
+    static_assert(CAND_WIN == 32, "the column sums below are laid out for 32 bins = 4 16-byte pieces per row");
+    typedef DType<DT> D_;
+    __shared__ uint32_t s_x[8][1024];
+    __shared__ uint32_t s_y[64][CAND_WIN];
+    __shared__ uint32_t s_part[16][2];
+    __shared__ uint32_t s_col[CAND_WIN + 2];
+    __shared__ uint32_t s_ok, s_bin, s_quota;
+    __shared__ uint32_t sm[16];
+    __shared__ uint32_t sm4[16][4];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const uint32_t guess = carry[0], served_fast = carry[4], served_full = carry[5];
+    float thr_old = 0.f;
+    if (threshold && t == 0) thr_old = D_::ld(reinterpret_cast<const typename D_::T*>(threshold));
+    const int per = (B + 1023) / 1024;
+    const int r0 = t * per, r1 = min(B, r0 + per);                   // REGS = false: this thread's rows
+    uint32_t cnt[4] = {0u, 0u, 0u, 0u};                              // REGS: candidates of rows t + 1024 j
+    uint32_t tot = 0, over = 0;
+    if (REGS) {
+        const int n16 = B * 4;                                       // 16-byte pieces of row_win
+        uint4 piece[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int u = i * 1024 + t;
+            piece[i] = (u < n16 && guess != 0) ? reinterpret_cast<const uint4*>(row_win)[u] : uint4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = t + 1024 * j;
+            cnt[j] = (r < B && guess != 0) ? cand_cnt[r] : 0u;
+            tot += cnt[j]; over |= cnt[j] > (uint32_t)C ? 1u : 0u;
+        }
+        // packed 16-bit adds over the thread's 16 pieces: exact whenever no row overflowed the compact matrix (a prefix
+        // count is then <= C = 1024, the sum <= 16384); with an overflowing row the verdict is "failed" from `over` alone
+        uint32_t ps[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { ps[0] += piece[i].x; ps[1] += piece[i].y; ps[2] += piece[i].z; ps[3] += piece[i].w; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s_x[k][t] = ps[k];
+        tot = wave_sum_u32(tot); over = wave_sum_u32(over);
+        if (lane == 0) { s_part[w][0] = tot; s_part[w][1] = over; }
+        __syncthreads();
+        // wave k adds word k of the threads l, l + 64, ... (same quarter q = l & 3 of the bins): bins 2 (4 q + k), + 1
+        if (w < 4) {
+            uint32_t lo = 0, hi = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { const uint32_t v = s_x[w][lane + 64 * j]; lo += v & 0xffffu; hi += v >> 16; }
+            s_y[lane][2 * w] = lo;
+            s_y[lane][2 * w + 1] = hi;
+        }
+        __syncthreads();
+        if (t < CAND_WIN) {
+            const int word = t >> 1, q = word >> 2, k = word & 3, h = t & 1;
+            uint32_t v = 0;
+#pragma unroll
+            for (int l = 0; l < 16; ++l) v += s_y[4 * l + q][2 * k + h];
+            s_col[t] = v;
+        }
+    } else {
+        uint32_t acc[CAND_WIN];
+#pragma unroll
+        for (int b = 0; b < CAND_WIN; ++b) acc[b] = 0;
+        if (guess != 0)
+            for (int r = r0; r < r1; ++r) {
+                const uint32_t n = cand_cnt[r];
+                tot += n; over |= n > (uint32_t)C ? 1u : 0u;
+                const uint4* p = reinterpret_cast<const uint4*>(row_win + (size_t)r * CAND_WIN);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint4 v = p[q];
+                    const uint32_t x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { acc[q * 8 + 2 * i] += x[i] & 0xffffu; acc[q * 8 + 2 * i + 1] += x[i] >> 16; }
+                }
+            }
+        tot = wave_sum_u32(tot); over = wave_sum_u32(over);
+        if (lane == 0) { s_part[w][0] = tot; s_part[w][1] = over; }
+        // wave c adds word c of the threads l, l + 64, ... (bank = lane), eight bins at a time
+#pragma unroll
+        for (int part = 0; part < 4; ++part) {
+            if (part) __syncthreads();
+#pragma unroll
+            for (int c = 0; c < 8; ++c) s_x[c][t] = acc[part * 8 + c];
+            __syncthreads();
+            if (w < 8) {
+                uint32_t v = 0;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) v += s_x[w][lane + 64 * k];
+                s_y[lane][part * 8 + w] = v;
+            }
+        }
+        __syncthreads();
+        if (t < CAND_WIN) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int l = 0; l < 64; ++l) v += s_y[l][t];
+            s_col[t] = v;
+        }
+    }
+    if (t >= CAND_WIN && t < CAND_WIN + 2) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v += s_part[i][t - CAND_WIN];
+        s_col[t] = v;
+    }
+    __syncthreads();
+    if (t == 0) {
+        tot = s_col[CAND_WIN]; over = s_col[CAND_WIN + 1];
+        uint32_t found = 0, bin = 0, above = 0;
+        if (guess != 0 && over == 0 && tot >= k_total) {
+            // entries above bin b: tot - S[b]; tau's bin is the highest one with at least k_total entries at or above it
+            for (int b = CAND_WIN - 2; b >= 0; --b) {
+                const uint32_t ab = tot - s_col[b];                // above bin b
+                if (ab >= k_total) break;                            // (b = 30: tau lies further up than the window resolves)
+                const uint32_t at = tot - (b ? s_col[b - 1] : 0u);   // at or above bin b
+                if (at >= k_total) { found = 1; bin = (uint32_t)b; above = ab; break; }
+            }
+        }
+        st->all_pos = 0;
+        for (int i = 0; i < 8; ++i) st->pad[i] = 0;
+        if (found) {
+            st->n_gt = above; st->k_rem = k_total - above; st->n_tie_take = k_total - above;
+            st->key_prefix = st->tau_bits = guess + (bin << 16);
+        } else {
+            st->key_prefix = 0; st->k_rem = k_total; st->n_gt = 0; st->tau_bits = 0; st->n_tie_take = 0;
+            st->min_sel_bits = 0xffffffffu; st->nnz = 0;
+        }
+        carry[1] = found; carry[2] = tot; carry[3] = over;
+        carry[4] = served_fast + found; carry[5] = served_full + 1u - found;
+        s_ok = found; s_bin = bin; s_quota = k_total - above;
+    }
+    __syncthreads();
+    if (!s_ok) {                                                     // uniform: the full-size launches take over
+        for (int i = t; i < 3 * HIST_BINS; i += 1024) hist[i] = 0;
+        return;
+    }
+    const uint32_t bin = s_bin, quota = s_quota;
+    uint32_t nnz_total;
+    if (REGS) {
+        // rows t + 1024 j: four row segments scanned side by side; ties are granted in ascending flat index, so a row takes
+        // what the quota has left after the rows before it (earlier segments first)
+        unsigned short at[4], below[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = min(t + 1024 * j, B - 1);
+            at[j] = row_win[(size_t)r * CAND_WIN + bin];
+            below[j] = bin ? row_win[(size_t)r * CAND_WIN + bin - 1] : (unsigned short)0;
+        }
+        uint32_t gt[4], eq[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool in = t + 1024 * j < B;
+            gt[j] = in ? cnt[j] - at[j] : 0u;
+            eq[j] = in ? (uint32_t)at[j] - below[j] : 0u;
+        }
+        uint32_t ex[4], totals[4];
+        block_excl_scan4_1024(eq, sm4, ex, totals);
+        uint32_t nn[4], take[4], seg = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t before = seg + ex[j];
+            take[j] = before >= quota ? 0u : min(eq[j], quota - before);
+            nn[j] = gt[j] + take[j];
+            seg += totals[j];
+        }
+        block_excl_scan4_1024(nn, sm4, ex, totals);
+        seg = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = t + 1024 * j;
+            if (r < B) { row_ptr[r] = (int32_t)(seg + ex[j]); tie_take[r] = take[j]; }
+            seg += totals[j];
+        }
+        nnz_total = seg;
+    } else {
+        uint32_t dummy, my_eq = 0;
+        for (int r = r0; r < r1; ++r) {
+            const uint32_t at = row_win[(size_t)r * CAND_WIN + bin], below = bin ? row_win[(size_t)r * CAND_WIN + bin - 1] : 0u;
+            row_gt[r] = cand_cnt[r] - at; row_eq[r] = at - below;
+            my_eq += at - below;
+        }
+        uint32_t run = block_excl_scan_1024(my_eq, sm, &dummy);
+        uint32_t my_nnz = 0;
+        for (int r = r0; r < r1; ++r) {
+            const uint32_t e = row_eq[r];
+            const uint32_t take = run >= quota ? 0u : min(e, quota - run);
+            tie_take[r] = take;
+            my_nnz += row_gt[r] + take;
+            run += e;
+        }
+        uint32_t base = block_excl_scan_1024(my_nnz, sm, &nnz_total);
+        for (int r = r0; r < r1; ++r) {
+            row_ptr[r] = (int32_t)base;
+            base += row_gt[r] + tie_take[r];
+        }
+    }
+    if (t == 0) {
+        row_ptr[B] = (int32_t)nnz_total;
+        st->nnz = nnz_total;
+        const uint32_t tau_bits = guess + (bin << 16);
+        st->min_sel_bits = tau_bits;                                 // with a tau the smallest selected value is tau (quota >= 1)
+        // next step's lower bound = tau lowered by 8 bf16 ulps (select_offsets_body)
+        const uint32_t margin = 8u << 16;
+        carry[0] = (nnz_total != 0 && tau_bits > margin + 0x00800000u && tau_bits <= 0x7f800000u) ? tau_bits - margin : 0u;
+        if (threshold && nnz_total != 0) {
+            // threshold_ema_body on the values at hand: (1 - lr) * threshold + lr * min_positive, each op rounded to the buffer dtype
+            const float a = D_::rnd((float)(1.0 - (double)lr) * thr_old);
+            const float b = D_::rnd(lr * __uint_as_float(tau_bits));
+            D_::st(reinterpret_cast<typename D_::T*>(threshold), D_::rnd(a + b));
+        }
+    }
+}
+
+// Fallback of the bf16 carried-bound select (carry[1] == 0: no bound yet, the bound failed, or tau lay beyond the window)
+// behind the full-size level-0 histogram: scan + per-row pass + tail as ONE launch, so a step served by the window pays for
+// two empty launches instead of four.  Every workgroup repeats the scan of the 4096 bins for itself (a pure function of
+// the histogram: tau's level-0 bin and the count above it), 16 rows per workgroup are counted as in
+// select_rowsub_bf16_kernel, and the workgroup whose ticket comes last -- every other one has then released its rows --
+// applies the scan to st and runs the single-workgroup tail (select_tail_kernel's pieces).  *ticket must be 0 at launch
+// (the window tail zeroes it together with the histograms).
+__global__ __launch_bounds__(1024) void select_fallback_rows_kernel(const void* __restrict__ acts, int B, int D,
+                                                                    mtc_select_state* st, const uint32_t* __restrict__ hist,
+                                                                    uint32_t* row_above, uint32_t* row_sub, uint32_t* row_gt,
+                                                                    uint32_t* row_eq, int32_t* __restrict__ row_ptr,
+                                                                    uint32_t* __restrict__ tie_take, uint32_t* carry,
+                                                                    void* threshold, float lr, const uint32_t* __restrict__ pred,
+                                                                    uint32_t* ticket) {
+    __shared__ uint32_t part[1024];
+    __shared__ uint32_t found_bin, found_above, s_last;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    if (*pred != 0) return;                            // uniform: the window tail served this call
+    // ---- scan (select_scan_kernel, level 0), results in LDS only
+    const uint32_t h0 = hist[4 * t], h1 = hist[4 * t + 1], h2 = hist[4 * t + 2], h3 = hist[4 * t + 3];
+    part[t] = h0 + h1 + h2 + h3;
+    if (t == 0) { found_bin = 0xffffffffu; found_above = 0; }
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const uint32_t add = (t + off < 1024) ? part[t + off] : 0u;
+        __syncthreads();
+        part[t] += add;
+        __syncthreads();
+    }
+    const uint32_t k_rem = st->k_rem;                  // = k_total: st was initialised by the launch before the histogram
+    {
+        uint32_t above = (t + 1 < 1024) ? part[t + 1] : 0u;
+        const uint32_t hs[4] = {h0, h1, h2, h3};
+#pragma unroll
+        for (int i = 3; i >= 0; --i) {
+            if (above < k_rem && k_rem <= above + hs[i]) { found_bin = 4 * t + i; found_above = above; }
+            above += hs[i];
+        }
+    }
+    __syncthreads();
+    const uint32_t total = part[0];
+    const bool all_pos = found_bin == 0xffffffffu;     // fewer positives than k: everything positive is selected
+    const uint32_t bin = found_bin;
+    // ---- per-row pass (select_rowsub_bf16_kernel), wave per row
+    const int row = blockIdx.x * 16 + w;
+    if (row < B) {
+        const size_t base = (size_t)row * D;
+        const int nch = D >> 3;
+        uint32_t above = 0, mn = 0xffffffffu;
+        uint32_t sub[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int c0 = lane; c0 < nch; c0 += 512) {
+            Raw<MTC_BF16> r[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (c0 + 64 * u < nch) r[u] = load_raw<MTC_BF16>(acts, base + (size_t)(c0 + 64 * u) * 8);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (c0 + 64 * u >= nch) break;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const uint32_t k = h ? (r[u].v[i] & 0xffff0000u) : (r[u].v[i] << 16);
+                        if (k == 0 || k > 0x7f800000u) continue;
+                        const uint32_t kb = k >> 19;
+                        if (all_pos || kb > bin) { ++above; mn = min(mn, k); }
+                        else if (kb == bin) {
+                            const uint32_t sidx = (k >> 16) & 7u;
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) sub[q] += (sidx == (uint32_t)q) ? 1u : 0u;
+                        }
+                    }
+                }
+            }
+        }
+        above = wave_sum_u32(above);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) sub[q] = wave_sum_u32(sub[q]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, o, 64));
+        if (lane == 0) {
+            row_above[row] = above;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) row_sub[(size_t)row * 8 + q] = sub[q];
+            if (all_pos) note_min_selected(st, mn);
+        }
+    }
+    // ---- hand-over: every wave's stores have left, one lane releases them and takes a ticket
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) {
+        __threadfence();
+        s_last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;                               // uniform
+    __threadfence();                                   // acquire: the other workgroups' rows, not this CU's cached lines
+    __syncthreads();
+    if (t == 0) {
+        if (all_pos) {
+            st->all_pos = 1; st->n_gt = total; st->tau_bits = 0; st->n_tie_take = 0; st->k_rem = 0;
+        } else {
+            st->n_gt += found_above;
+            st->k_rem = k_rem - found_above;
+            st->key_prefix |= bin << 19;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    select_finish_body(B, st, row_above, row_sub, nullptr, row_gt, row_eq);
+    __threadfence_block();
+    __syncthreads();
+    select_offsets_body(B, row_gt, row_eq, nullptr, st, row_ptr, tie_take, carry);
+    if (threshold && t == 0) threshold_ema_body<MTC_BF16>(st, threshold, lr);
 }
 
 template <int DT>
@@ -1355,7 +1750,8 @@ extern "C" size_t mtc_select_carry_workspace_bytes(const mtc_desc* d) {
     const size_t es = d->dtype == MTC_BF16 ? 2 : 4;
     const size_t cells = (size_t)d->B * carry_cols(d);
     return ((mtc_select_workspace_bytes(d) + 255) & ~(size_t)255) + ((cells * es + 255) & ~(size_t)255) +
-           ((cells * sizeof(int32_t) + 255) & ~(size_t)255) + (size_t)d->B * sizeof(uint32_t);
+           ((cells * sizeof(int32_t) + 255) & ~(size_t)255) + (((size_t)d->B * sizeof(uint32_t) + 255) & ~(size_t)255) +
+           (size_t)d->B * CAND_WIN * sizeof(unsigned short);
 }
 
 extern "C" int mtc_select_global_topk_carry(const mtc_desc* d, const void* acts, uint32_t k_total, void* workspace,
@@ -1397,32 +1793,55 @@ extern "C" int mtc_select_global_topk_carry_marked(const mtc_desc* d, const void
     int32_t* cand_cols = reinterpret_cast<int32_t*>(cand_vals + (((size_t)d->B * C * es + 255) & ~(size_t)255));
     uint32_t* cand_cnt = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(cand_cols) +
                                                      (((size_t)d->B * C * sizeof(int32_t) + 255) & ~(size_t)255));
+    unsigned short* row_win = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(cand_cnt) +
+                                                                 (((size_t)d->B * sizeof(uint32_t) + 255) & ~(size_t)255));
     const uint32_t* flag = carry + 1;
     int rc;
+    if (d->dtype == MTC_BF16) {
+        // candidate pass (+ per-row window counts) -> ONE single-workgroup launch that finds tau, the quota, the CSR offsets,
+        // the next bound and the threshold EMA from those counts -> ordered fill from the compact matrix.  The two
+        // launches in between are the fallback (bound failed / tau beyond the window): full-size passes that leave at once
+        // when carry[1] == 1; the fill reads the compact matrix or acts accordingly.  Nothing is read back.
+        hipLaunchKernelGGL(select_candidates_kernel<MTC_BF16>, dim3((d->B + 3) / 4), dim3(256), 0, s, acts, d->B, d->D, C,
+                           (const uint32_t*)carry, (void*)cand_vals, cand_cols, cand_cnt,
+                           reinterpret_cast<const unsigned char*>(marks), row_win);
+        if (d->B <= 4096)
+            hipLaunchKernelGGL((select_window_tail_kernel<MTC_BF16, true>), dim3(1), dim3(1024), 0, s, d->B, C, k_total, st,
+                               carry, (const uint32_t*)cand_cnt, (const unsigned short*)row_win, hist, row_gt, row_eq, row_ptr,
+                               tie_take, threshold, ema_lr);
+        else
+            hipLaunchKernelGGL((select_window_tail_kernel<MTC_BF16, false>), dim3(1), dim3(1024), 0, s, d->B, C, k_total, st,
+                               carry, (const uint32_t*)cand_cnt, (const unsigned short*)row_win, hist, row_gt, row_eq, row_ptr,
+                               tie_take, threshold, ema_lr);
+        if ((rc = check_launch("mtc_select_global_topk_carry"))) return rc;
+        if ((rc = hist_impl(d, d->D, acts, 0, st, hist, flag, 0, stream))) return rc;
+        hipLaunchKernelGGL(select_fallback_rows_kernel, dim3((d->B + 15) / 16), dim3(1024), 0, s, acts, d->B, d->D, st,
+                           (const uint32_t*)hist, row_above, row_sub, row_gt, row_eq, row_ptr, tie_take, carry, threshold, ema_lr,
+                           flag, hist + HIST_BINS /* ticket: a word of the unused level-1 histogram, zeroed with it */);
+        if ((rc = check_launch("mtc_select_global_topk_carry"))) return rc;
+        return fill_impl(d, C, cand_vals, st, nullptr, row_ptr, tie_take, col_idx, vals, cand_cols, flag, 1, stream, acts, d->D);
+    }
     // one pass over acts with the carried bound, then the verdict (flag) for the launches below
-    DISPATCH_DT(d->dtype, select_candidates_kernel, dim3((d->B + 3) / 4), dim3(256), 0, s, acts, d->B, d->D, C, carry,
-                (void*)cand_vals, cand_cols, cand_cnt, reinterpret_cast<const unsigned char*>(marks));
+    hipLaunchKernelGGL(select_candidates_kernel<MTC_F32>, dim3((d->B + 3) / 4), dim3(256), 0, s, acts, d->B, d->D, C,
+                       (const uint32_t*)carry, (void*)cand_vals, cand_cols, cand_cnt,
+                       reinterpret_cast<const unsigned char*>(marks), (unsigned short*)nullptr);
     hipLaunchKernelGGL(select_carry_decide_kernel, dim3(1), dim3(1024), 0, s, carry, cand_cnt, d->B, C, k_total, st, hist);
     if ((rc = check_launch("mtc_select_global_topk_carry"))) return rc;
     // each streaming pass is ONE launch that reads the compact matrix if flag == 1 and acts if flag == 0 (grid sized for
     // the larger); the scans between them work on the shared histogram / per-row arrays whichever matrix filled them
-    if (d->dtype == MTC_BF16) {
-        if ((rc = hist_impl(d, C, cand_vals, 0, st, hist, flag, 1, stream, acts, d->D))) return rc;
-        if ((rc = mtc_select_scan(d, 0, hist, st, stream))) return rc;
-        if ((rc = rowsub_impl(d, C, cand_vals, st, row_above, row_sub, flag, 1, stream, acts, d->D))) return rc;
-    } else {
-        const int levels = mtc_select_levels(d);
-        for (int l = 0; l < levels; ++l) {
-            if ((rc = hist_impl(d, C, cand_vals, l, st, hist + l * HIST_BINS, flag, 1, stream, acts, d->D))) return rc;
-            if ((rc = mtc_select_scan(d, l, hist + l * HIST_BINS, st, stream))) return rc;
-        }
-        if ((rc = count_impl(d, C, cand_vals, st, nullptr, row_gt, row_eq, flag, 1, stream, acts, d->D))) return rc;
+    // (fp32: 32-bit keys, three histogram levels on whichever matrix the flag names)
+    const int levels = mtc_select_levels(d);
+    for (int l = 0; l < levels; ++l) {
+        if ((rc = hist_impl(d, C, cand_vals, l, st, hist + l * HIST_BINS, flag, 1, stream, acts, d->D))) return rc;
+        if ((rc = mtc_select_scan(d, l, hist + l * HIST_BINS, st, stream))) return rc;
     }
-    // one launch: [bf16: finish] + offsets + next bound + [threshold EMA].  With a tau the smallest selected value is tau,
-    // noted by the offsets piece; without one (fewer positives than k) the rowsub / count pass noted it -- either way
+    if ((rc = count_impl(d, C, cand_vals, st, nullptr, row_gt, row_eq, flag, 1, stream, acts, d->D))) return rc;
+    // one launch: offsets + next bound + [threshold EMA].  With a tau the smallest selected value is tau,
+    // noted by the offsets piece; without one (fewer positives than k) the count pass noted it -- either way
     // st->min_sel_bits is final before the fill, which does not touch it in TopK mode
-    DISPATCH_DT(d->dtype, select_tail_kernel, dim3(1), dim3(1024), 0, s, d->B, st, d->dtype == MTC_BF16 ? 1 : 0,
-                (const uint32_t*)row_above, (const uint32_t*)row_sub, row_gt, row_eq, row_ptr, tie_take, carry, threshold, ema_lr);
+    hipLaunchKernelGGL(select_tail_kernel<MTC_F32>, dim3(1), dim3(1024), 0, s, d->B, st, 0,
+                (const uint32_t*)row_above, (const uint32_t*)row_sub, row_gt, row_eq, row_ptr, tie_take, carry, threshold, ema_lr,
+                (const uint32_t*)nullptr, 0u);
     if ((rc = check_launch("mtc_select_global_topk_carry"))) return rc;
     return fill_impl(d, C, cand_vals, st, nullptr, row_ptr, tie_take, col_idx, vals, cand_cols, flag, 1, stream, acts, d->D);
 }

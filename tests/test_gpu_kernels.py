@@ -357,6 +357,15 @@ def test_select_carry_is_identical_to_full_select(dt, gpu_lib):
         carry[0] = 0
         run_pair(acts3); run_pair(acts3)
         assert carry[4].item() == 3
+        # tau rises ~75 bf16 ulps in one step: every entry >= tau is a candidate, but tau lies beyond the 31-ulp window the
+        # fast path resolves -> full passes; the next call, with the refreshed bound, is served by the window again
+        acts4 = (acts2.float() * 1.5).to(dt)
+        run_pair(acts2)
+        served = carry[4].item()
+        run_pair(acts4)
+        assert carry[4].item() == served and carry[2].item() >= k * B and carry[3].item() == 0
+        run_pair(acts4)
+        assert carry[4].item() == served + 1
     served = carry[4].item()
     run_pair((acts.float() * 0.25).to(dt))              # 4: bound far too high -> fewer than k candidates -> full
     assert carry[4].item() == served
@@ -374,6 +383,30 @@ def test_select_carry_is_identical_to_full_select(dt, gpu_lib):
     car = hp.select_topk(d, acts6, k * B, carry=True)
     assert torch.equal(full.row_ptr, car.row_ptr) and int(car.row_ptr[-1]) == 4 * B
     assert carry[0].item() == 0
+
+
+@pytest.mark.parametrize("B", [1000, 4096, 4104])
+def test_select_carry_window_tail_row_counts(B, gpu_lib):
+    """bf16 fast path at batch sizes on both sides of the register-resident tail's limit (4 rows per thread): B = 4104
+    runs the looping form of the same launch.  Identical to the full select, served by the window from the second call."""
+    from matryoshka_transcoder_amd.engine import HotPath
+    torch.manual_seed(B)
+    D, k = 512, 6
+    hp = HotPath(64, 64, [D], torch.bfloat16, False)
+    d = hp.desc(B)
+    carry = hp.carry_state(torch.device("cuda:0"))
+    carry.zero_()
+    base = torch.relu(torch.randn(B, D, device="cuda"))
+    for i, scale in enumerate((1.0, 1.02, 0.99, 1.0)):
+        acts = (base * scale).to(torch.bfloat16)
+        full = hp.select_topk(d, acts, k * B)
+        car = hp.select_topk(d, acts, k * B, carry=True)
+        torch.cuda.synchronize()
+        nnz = int(full.row_ptr[-1])
+        assert nnz == k * B
+        for a, b, name in zip(_sel_tuple(car, nnz), _sel_tuple(full, nnz), ("state", "row_ptr", "col_idx", "vals")):
+            assert torch.equal(a[:8] if name == "state" else a, b[:8] if name == "state" else b), (i, name)
+        assert carry[4].item() == i                     # call 0 has no bound; every later one is served by the window
 
 
 @pytest.mark.parametrize("dt,A", [(torch.bfloat16, 768), (torch.float32, 512), (torch.bfloat16, 2304),
