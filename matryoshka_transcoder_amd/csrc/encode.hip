@@ -627,7 +627,7 @@ __device__ __forceinline__ void lid_to_tile(int lid, int mt, int nt, int& tm, in
 #ifdef MTC_ENCODE_STAMPS
 // Diagnostic build only (tools/encode_stamps.sh builds a separate libmtc_diag.so): per-wave cycle accounting of the
 // persistent encoder.  Stamp values go to a buffer of their own; no output value depends on them.
-__device__ unsigned long long g_enc_stamps[2 * 256 * 8 * 8];
+__device__ unsigned long long g_enc_stamps[3 * 256 * 8 * 8];
 #define STAMP() __builtin_amdgcn_s_memtime()
 #endif
 
@@ -691,6 +691,7 @@ __global__ __launch_bounds__(512, 1) void encode_bf16_mfma256p_kernel(const u16*
     unsigned long long t_epi = 0, t_first_wait = 0, t_other_wait = 0, t_loop0 = 0, t_first_bar = 0;
     bool after_epi = false;
     unsigned long long t_iv[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0;
+    unsigned long long t_p0_issue = 0, t_p3_issue = 0, t_p3_wait = 0, t_m0 = 0;
 #endif
 
     // ---- staging: half-tile h has 16 pieces of 8 rows x 128 B; wave wid moves pieces 2 wid, 2 wid + 1 of every half
@@ -698,16 +699,14 @@ __global__ __launch_bounds__(512, 1) void encode_bf16_mfma256p_kernel(const u16*
     const int pch0 = ((lane & 7) ^ ((prow0 >> 1) & 7)) * 8, pch1 = ((lane & 7) ^ ((prow1 >> 1) & 7)) * 8;
     const u16* wsrc[2][2];
     const u16* xsrc[2][2];
-    auto set_w = [&](int lid) {
+    auto set_wh = [&](int lid, int h) {
         int tm, tn;
         lid_to_tile(lid, mt, nt, tm, tn);
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const long long ld = EPI == 0 ? (long long)K : ldb;
-            wsrc[h][0] = Wt + (size_t)min(tn * B2N + h * 128 + prow0, N - 1) * ld + pch0;    // clamp: tails read valid rows
-            wsrc[h][1] = Wt + (size_t)min(tn * B2N + h * 128 + prow1, N - 1) * ld + pch1;
-        }
+        const long long ld = EPI == 0 ? (long long)K : ldb;
+        wsrc[h][0] = Wt + (size_t)min(tn * B2N + h * 128 + prow0, N - 1) * ld + pch0;    // clamp: tails read valid rows
+        wsrc[h][1] = Wt + (size_t)min(tn * B2N + h * 128 + prow1, N - 1) * ld + pch1;
     };
+    auto set_w = [&](int lid) { set_wh(lid, 0); set_wh(lid, 1); };
     auto set_x = [&](int lid) {
         int tm, tn;
         lid_to_tile(lid, mt, nt, tm, tn);
@@ -736,7 +735,14 @@ __global__ __launch_bounds__(512, 1) void encode_bf16_mfma256p_kernel(const u16*
     };
     // the two operand streams run ahead of the MFMAs by one (W) / two (X) k-steps and cross tile boundaries
     int wk = 0, wm = 0, xk = 0, xm = 0;                                           // next stage to issue: k-tile, tile ordinal
+#ifdef MTC_ENC_W0_AHEAD
+    // W half 0 runs two k-steps ahead (staged in phase 3 beside X), W half 1 one k-step ahead (phase 1): phase 0 issues no LDS-DMA
+    int w0k = 0, w0m = 0;
+    auto adv_w0 = [&]() { if (++w0k == ktiles) { w0k = 0; if (++w0m < count) set_wh(first + w0m * stride, 0); } };
+    auto adv_w = [&]() { if (++wk == ktiles) { wk = 0; if (++wm < count) set_wh(first + wm * stride, 1); } };
+#else
     auto adv_w = [&]() { if (++wk == ktiles) { wk = 0; if (++wm < count) set_w(first + wm * stride); } };
+#endif
     auto adv_x = [&]() { if (++xk == ktiles) { xk = 0; if (++xm < count) set_x(first + xm * stride); } };
 
     const int fr = lane & 15, fq = lane >> 4;
@@ -757,10 +763,18 @@ __global__ __launch_bounds__(512, 1) void encode_bf16_mfma256p_kernel(const u16*
     // prologue (first tile only): step 0 entirely, plus the X halves of step 1
     set_w(first); set_x(first);
     stage_w(0, 0, 0); stage_w(0, 1, 0); adv_w();
+#ifdef MTC_ENC_W0_AHEAD
+    adv_w0();
+#endif
     stage_x(0, 0, 0); stage_x(0, 1, 0); adv_x();
     if (S > 1) {
         stage_x(1, 0, xk); stage_x(1, 1, xk); adv_x();
+#ifdef MTC_ENC_W0_AHEAD
+        stage_w(1, 0, w0k); adv_w0();
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+#else
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+#endif
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -799,11 +813,17 @@ __global__ __launch_bounds__(512, 1) void encode_bf16_mfma256p_kernel(const u16*
 #pragma unroll
             for (int i = 0; i < 4; ++i) wf[ks][i] = *reinterpret_cast<const bf16x8*>(cur + w_base + i * 16 * 128 + off[ks]);
         }
-#if !defined(MTC_ENC_STAGE_W_P1) && MTC_ENC_P0_ORDER == 0
+#if !defined(MTC_ENC_STAGE_W_P1) && MTC_ENC_P0_ORDER == 0 && !defined(MTC_ENC_W0_AHEAD)
         if (more) stage_w(nb, 0, wk);
+#endif
+#ifdef MTC_ENCODE_STAMPS
+        { const unsigned long long ts_ = STAMP(); t_p0_issue += ts_ - t_prev; }
 #endif
         PFENCE(0);
         mfma_quadrant<0, 0>(wf, xa, acc);
+#ifdef MTC_ENCODE_STAMPS
+        { const unsigned long long ts_ = STAMP(); t_m0 += ts_ - t_prev; }
+#endif
         PFENCE(1);
         // ---------------- phase 1
 #pragma unroll
@@ -831,7 +851,21 @@ __global__ __launch_bounds__(512, 1) void encode_bf16_mfma256p_kernel(const u16*
 #endif
         if (more2) {
             stage_x(it & 1, 0, xk); stage_x(it & 1, 1, xk); adv_x();
+#ifdef MTC_ENC_W0_AHEAD
+            stage_w(it & 1, 0, w0k); adv_w0();
+#endif
+#ifdef MTC_ENCODE_STAMPS
+            __builtin_amdgcn_sched_barrier(0);
+            { const unsigned long long ts_ = STAMP(); t_p3_issue += ts_ - tw0; t_p3_wait -= ts_; }
+#endif
+#ifdef MTC_ENC_W0_AHEAD
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+#else
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                     // everything older (all of step it+1, earlier stores) is done
+#endif
+#ifdef MTC_ENCODE_STAMPS
+            t_p3_wait += STAMP();
+#endif
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -937,6 +971,8 @@ __global__ __launch_bounds__(512, 1) void encode_bf16_mfma256p_kernel(const u16*
         o[5] = __builtin_amdgcn_s_memrealtime() - rt_start; o[6] = t_first_bar; o[7] = (unsigned long long)count;
         unsigned long long* o2 = g_enc_stamps + 256 * 8 * 8 + ((size_t)(bid & 255) * 8 + wid) * 8;
         for (int i = 0; i < 8; ++i) o2[i] = t_iv[i];
+        unsigned long long* o3 = g_enc_stamps + 2 * 256 * 8 * 8 + ((size_t)(bid & 255) * 8 + wid) * 8;
+        o3[0] = t_p0_issue; o3[1] = t_p3_issue; o3[2] = t_p3_wait; o3[3] = t_m0; o3[4] = 0; o3[5] = 0; o3[6] = 0; o3[7] = 0;
     }
 #endif
 }

@@ -31,7 +31,7 @@ acts = torch.empty(B, D, dtype=dt, device="cuda")
 for _ in range(200):          # a second or so of back-to-back launches first (clock settles under load)
     lib.mtc_encode_fwd(C.byref(d), _p(x), _p(W), _p(b), _p(acts), _stream())
 torch.cuda.synchronize()
-n = 2 * 256 * 8 * 8
+n = 3 * 256 * 8 * 8
 buf = (C.c_ulonglong * n)()
 fn = lib.mtc_diag_read_encode_stamps
 fn.argtypes = [C.POINTER(C.c_ulonglong), C.c_size_t]
@@ -48,4 +48,9 @@ for w in (0, 4):
     steps = med[7] * (A // 64)
     # interval i = from barrier i to barrier i+1 of a k-step, cycles per step (barrier 7 -> next step's barrier 0 is interval 0)
     out[f"wave{w}"]["cycles_per_interval"] = [round(statistics.median(r[i] for r in iv) / steps, 1) for i in range(8)]
+    ex = [[buf[2 * 256 * 64 + (wg * 8 + w) * 8 + i] for i in range(4)] for wg in range(256)]
+    # inside the wave's own slots, cycles per k-step: phase 0's load slot up to its barrier, phase 3's staging issue and
+    # counted wait, and the MFMA cluster of phase 0 (from behind barrier 0 to in front of barrier 1, fragment wait included)
+    out[f"wave{w}"]["within_slots"] = dict(zip(["phase0_issue", "phase3_stage_issue", "phase3_vmcnt_wait", "phase0_mfma_slot"],
+                                               [round(statistics.median(r[i] for r in ex) / steps, 1) for i in range(4)]))
 print(json.dumps(out, indent=1))
