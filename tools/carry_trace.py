@@ -12,6 +12,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--aux-active", action="store_true")
     ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--pool", type=int, default=8)
     args = ap.parse_args()
     from matryoshka_transcoder_amd.training import FusedAdam
     from matryoshka_transcoder_amd.transcoder import MatryoshkaTranscoder
@@ -27,7 +28,7 @@ def main():
         cnt = tc.num_batches_not_active
         cnt[forced] = float(cfg["n_batches_to_dead"])
         tc.num_batches_not_active = cnt
-    pool = bench.batch_pool(B, A, torch.bfloat16, dev)
+    pool = bench.batch_pool(B, A, torch.bfloat16, dev, n=args.pool)
     hp = tc.hot_path()
     for i in range(args.steps):
         xs, xt = pool[i % len(pool)]

@@ -101,7 +101,8 @@ work = {   # kernel-name prefix -> (bound, algorithmic work, compulsory bytes or
                                      "W_enc / moment rows read + written once, gather of nnz rows of x (L2-resident slices)"),
     "mtc::csc_": ("latency", NNZ * 16, NNZ * 16, "CSC build: count / scan / fill / sort, summed"),
     "mtc::colsum_": ("hbm", B * A * S_, B * A * S_, "db_dec column sums, both launches"),
-    "mtc::select_": ("latency", 0, 0, "exact select on the compact candidate matrix (hist / scan / rowsub / tail / fill), summed"),
+    "mtc::select_": ("latency", 0, 0, "exact select behind the candidate pass, summed: window tail (tau, quota, offsets from per-row window counts; one workgroup), "
+                     "two predicated fallback launches that leave at once, ordered fill"),
 }
 stats = {}
 for r in csv.DictReader(open(f"profiles/{tag}_kernel_stats.csv")):
