@@ -421,6 +421,17 @@ class HotPath:
         B, dev = acts_aux.shape[0], acts_aux.device
         if g_loss is not None:
             g_aux = (g_aux.float() * g_loss.reshape(()).float()).to(self.dtype)
+        ctx["enc_rows_event"] = None
+        main = torch.cuda.current_stream()
+        x_normT = None
+        if side is not None:
+            # the transpose of the step's input depends on nothing the branch computes: side stream, at once
+            e_in = torch.cuda.Event()
+            e_in.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(e_in)
+                x_normT = self.transpose_rows(x_norm, B, self.A_s)                                 # [A_s][B]
+        g_auxT = self.transpose_rows(g_aux, B, self.A_t)                                           # [A_t][B]
         # d_acts^T [n_pad][B] = W_dec[dead] . g_aux^T, masked by the selection, and its row sums (b_enc elements)
         d_actsT = torch.empty(n_pad, B, dtype=self.dtype, device=dev)
         self.gemm_nt(n_pad, B, self.A_t, W_dec, self.A_t, g_aux, self.A_t, d_actsT, B, a_rows=dead.dead_idx)
@@ -428,32 +439,28 @@ class HotPath:
         e_b = torch.empty(n_pad, dtype=self.dtype, device=dev)
         check(self.lib.mtc_aux_mask_rowsum(self.code, n_pad, B, _p(acts_auxT), B, _p(d_actsT), B, _p(e_b), _stream()),
               "mtc_aux_mask_rowsum")
-        def enc_rows():
-            x_normT = self.transpose_rows(x_norm, B, self.A_s)                                     # [A_s][B]
-            E = torch.empty(n_pad, self.A_s, dtype=self.dtype, device=dev)
-            self.gemm_nt(n_pad, self.A_s, B, d_actsT, B, x_normT, B, E, self.A_s)
-            return E, x_normT
-
-        g_auxT = self.transpose_rows(g_aux, B, self.A_t)                                           # [A_t][B]
         E_dec = torch.empty(n_pad, self.A_t, dtype=self.dtype, device=dev)
-        self.gemm_nt(n_pad, self.A_t, B, acts_auxT, B, g_auxT, B, E_dec, self.A_t)
-        ctx["enc_rows_event"] = None
         if side is None:
-            E_enc, _ = enc_rows()
+            self.gemm_nt(n_pad, self.A_t, B, acts_auxT, B, g_auxT, B, E_dec, self.A_t)
+            x_normT = self.transpose_rows(x_norm, B, self.A_s)
+            E_enc = torch.empty(n_pad, self.A_s, dtype=self.dtype, device=dev)
+            self.gemm_nt(n_pad, self.A_s, B, d_actsT, B, x_normT, B, E_enc, self.A_s)
         else:
-            # the encoder rows are not needed before the SECOND gradient launch: their transpose + product run on the side
-            # stream beside the decoder-row launch (an MFMA-bound product under a fabric-bound gather kernel; started
-            # behind the E_dec product, which it would only slow down).  Operands the side stream reads / writes stay
-            # referenced in ctx until the next step (allocator safety across streams).
-            main = torch.cuda.current_stream()
-            e_dec = torch.cuda.Event()
-            e_dec.record(main)
+            # the two gradient products have the same shape and neither fills the chip (198 tiles of 256 x 256 on 256 CUs at
+            # config #2): E_dec is launched first, on the main stream, the encoder rows follow on the side stream through a
+            # cross-queue wait (~10 us later), take the CUs E_dec leaves idle and the ones it frees, and finish under the head
+            # of the decoder-row launch, which does not need them (the encoder-row launch waits for enc_rows_event).
+            # Operands the side stream reads / writes stay referenced in ctx until the next step (allocator safety).
+            e_mask = torch.cuda.Event()
+            e_mask.record(main)
+            self.gemm_nt(n_pad, self.A_t, B, acts_auxT, B, g_auxT, B, E_dec, self.A_t)
             with torch.cuda.stream(side):
-                side.wait_event(e_dec)
-                E_enc, x_normT = enc_rows()
+                side.wait_event(e_mask)
+                E_enc = torch.empty(n_pad, self.A_s, dtype=self.dtype, device=dev)
+                self.gemm_nt(n_pad, self.A_s, B, d_actsT, B, x_normT, B, E_enc, self.A_s)
                 ctx["enc_rows_event"] = torch.cuda.Event()
                 ctx["enc_rows_event"].record(side)
-            ctx["enc_rows_keep"] = (d_actsT, x_normT, E_enc)
+            ctx["enc_rows_keep"] = (d_actsT, x_normT, E_enc, x_norm)
         return E_dec, E_enc, e_b
 
     def aux_backward_dense(self, ctx, x_norm, g_loss, grads):
