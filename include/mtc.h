@@ -301,6 +301,13 @@ size_t mtc_csc_workspace_bytes(const mtc_desc* d);
 int mtc_build_csc(const mtc_desc* d, const int32_t* row_ptr, const int32_t* col_idx,
                   void* workspace, size_t workspace_bytes, int32_t* col_ptr, int32_t* csc_row,
                   int32_t* csc_pos, float* cnt, void* stream);
+/* The same in two enqueues on one workspace (mtc_build_csc = part 1, then part 2): part 1 leaves col_ptr and the updated
+ * counters cnt (sae.py:165-169) behind, part 2 fills and orders csc_row / csc_pos.  A step with the auxiliary loss active
+ * enqueues mtc_aux_dead_list between the two, so that the dead list (sae.py:330-331) is ready before the decode launch
+ * that runs beside this chain has drained. */
+int mtc_build_csc_part(const mtc_desc* d, const int32_t* row_ptr, const int32_t* col_idx,
+                       void* workspace, size_t workspace_bytes, int32_t* col_ptr, int32_t* csc_row,
+                       int32_t* csc_pos, float* cnt, int32_t part, void* stream);
 
 /* a11  k-sparse backward (autograd of sae.py:173-245, training.py:172), one wavefront per feature:
  *   dW_dec[j]  = scale * sum_b a_bj g_b          dW_encT[j] = scale * sum_b d_a_bj x_b

@@ -76,6 +76,7 @@ PROTOTYPES = {
     "mtc_decode_bwd_vals": (C.c_int, [DP, P, P, P, P, C.c_float, P, P]),
     "mtc_csc_workspace_bytes": (C.c_size_t, [DP]),
     "mtc_build_csc": (C.c_int, [DP, P, P, P, C.c_size_t, P, P, P, P, P]),
+    "mtc_build_csc_part": (C.c_int, [DP, P, P, P, C.c_size_t, P, P, P, P, C.c_int32, P]),
     "mtc_backward_sparse": (C.c_int, [DP, P, P, P, P, P, P, P, P, P, P, P, C.c_int, P]),
     "mtc_colsum_workspace_bytes": (C.c_size_t, [DP]),
     "mtc_colsum": (C.c_int, [DP, P, P, P, C.c_size_t, P, C.c_int, P]),

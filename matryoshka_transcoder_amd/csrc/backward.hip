@@ -298,10 +298,13 @@ extern "C" size_t mtc_csc_workspace_bytes(const mtc_desc* d) {
     return 3 * (size_t)d->D * sizeof(uint32_t) + 4096 + (size_t)long_sort_blocks(d) * d->B * sizeof(int32_t);
 }
 
-extern "C" int mtc_build_csc(const mtc_desc* d, const int32_t* row_ptr, const int32_t* col_idx, void* workspace,
-                             size_t workspace_bytes, int32_t* col_ptr, int32_t* csc_row, int32_t* csc_pos, float* cnt,
-                             void* stream) {
+// part 1: counts -> column pointers, cursors, dead counters (everything the dead-feature list needs); part 2: fill + per-column
+// order.  mtc_build_csc runs both; a caller that wants the dead list early enqueues it between the two (same workspace).
+extern "C" int mtc_build_csc_part(const mtc_desc* d, const int32_t* row_ptr, const int32_t* col_idx, void* workspace,
+                                  size_t workspace_bytes, int32_t* col_ptr, int32_t* csc_row, int32_t* csc_pos, float* cnt,
+                                  int32_t part, void* stream) {
     if (check_desc(d, "mtc_build_csc")) return -1;
+    MTC_REQUIRE(part == 1 || part == 2, "mtc_build_csc_part: part must be 1 or 2");
     MTC_REQUIRE(row_ptr && col_idx && workspace && col_ptr && csc_row && csc_pos, "mtc_build_csc: null pointer");
     MTC_REQUIRE(workspace_bytes >= mtc_csc_workspace_bytes(d), "mtc_build_csc: workspace too small");
     MTC_REQUIRE(d->B <= 65536, "mtc_build_csc: B > 65536 unsupported");
@@ -315,20 +318,30 @@ extern "C" int mtc_build_csc(const mtc_desc* d, const int32_t* row_ptr, const in
     int32_t* long_list = reinterpret_cast<int32_t*>(cursor + d->D);
     int32_t* slots = long_list + d->D;
     hipStream_t s = as_stream(stream);
-    if (hipMemsetAsync(workspace, 0, (1024 + (size_t)d->D) * sizeof(uint32_t), s) != hipSuccess) {
-        set_error("mtc_build_csc: memset failed");
-        return -2;
-    }
     const dim3 rgrid((d->B + 3) / 4), block(256);
-    hipLaunchKernelGGL(csc_count_kernel, rgrid, block, 0, s, d->B, row_ptr, col_idx, counts);
-    hipLaunchKernelGGL(csc_tile_sum_kernel, dim3(n_tiles), dim3(1024), 0, s, d->D, counts, tile_sum);
-    hipLaunchKernelGGL(csc_scan_kernel, dim3(n_tiles), dim3(1024), 0, s, d->D, n_tiles, counts, tile_sum, col_ptr, cursor, cnt,
-                       long_list, n_long);
-    hipLaunchKernelGGL(csc_fill_kernel, rgrid, block, 0, s, d->B, row_ptr, col_idx, cursor, csc_row, csc_pos);
-    hipLaunchKernelGGL(csc_sort_kernel, dim3((d->D + 3) / 4), block, 0, s, d->D, col_ptr, csc_row, csc_pos);
-    hipLaunchKernelGGL(csc_sort_long_kernel, dim3(long_sort_blocks(d)), block, 0, s, d->B, col_ptr, long_list, n_long, csc_row,
-                       csc_pos, slots);
+    if (part == 1) {
+        if (hipMemsetAsync(workspace, 0, (1024 + (size_t)d->D) * sizeof(uint32_t), s) != hipSuccess) {
+            set_error("mtc_build_csc: memset failed");
+            return -2;
+        }
+        hipLaunchKernelGGL(csc_count_kernel, rgrid, block, 0, s, d->B, row_ptr, col_idx, counts);
+        hipLaunchKernelGGL(csc_tile_sum_kernel, dim3(n_tiles), dim3(1024), 0, s, d->D, counts, tile_sum);
+        hipLaunchKernelGGL(csc_scan_kernel, dim3(n_tiles), dim3(1024), 0, s, d->D, n_tiles, counts, tile_sum, col_ptr, cursor, cnt,
+                           long_list, n_long);
+    } else {
+        hipLaunchKernelGGL(csc_fill_kernel, rgrid, block, 0, s, d->B, row_ptr, col_idx, cursor, csc_row, csc_pos);
+        hipLaunchKernelGGL(csc_sort_kernel, dim3((d->D + 3) / 4), block, 0, s, d->D, col_ptr, csc_row, csc_pos);
+        hipLaunchKernelGGL(csc_sort_long_kernel, dim3(long_sort_blocks(d)), block, 0, s, d->B, col_ptr, long_list, n_long, csc_row,
+                           csc_pos, slots);
+    }
     return check_launch("mtc_build_csc");
+}
+
+extern "C" int mtc_build_csc(const mtc_desc* d, const int32_t* row_ptr, const int32_t* col_idx, void* workspace,
+                             size_t workspace_bytes, int32_t* col_ptr, int32_t* csc_row, int32_t* csc_pos, float* cnt,
+                             void* stream) {
+    const int rc = mtc_build_csc_part(d, row_ptr, col_idx, workspace, workspace_bytes, col_ptr, csc_row, csc_pos, cnt, 1, stream);
+    return rc ? rc : mtc_build_csc_part(d, row_ptr, col_idx, workspace, workspace_bytes, col_ptr, csc_row, csc_pos, cnt, 2, stream);
 }
 
 #define LAUNCH_GRAD(DTV, COEF, ncv)                                                                                  \

@@ -61,6 +61,7 @@ class Selection:
     col_ptr: Optional[torch.Tensor] = None
     csc_row: Optional[torch.Tensor] = None
     csc_pos: Optional[torch.Tensor] = None
+    _csc_ws: Optional[torch.Tensor] = None      # workspace of a CSC build between its two parts
 
 
 @dataclass
@@ -217,18 +218,29 @@ class HotPath:
         check(self.lib.mtc_threshold_ema(C.byref(d), _p(sel.state), _p(threshold), float(lr), _stream()), "mtc_threshold_ema")
 
     # ------------------------------------------------------------------ a7 + CSC
-    def build_csc(self, d, sel: Selection, dead_cnt: Optional[torch.Tensor]):
+    def build_csc(self, d, sel: Selection, dead_cnt: Optional[torch.Tensor], part: int = 0):
+        """a7 + the feature-major index.  part = 1 / 2: the two halves as separate enqueues (the counters are final after
+        part 1: a caller may put the dead-feature list between them)."""
         dev = sel.row_ptr.device
         ws_bytes = self.lib.mtc_csc_workspace_bytes(C.byref(d))
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        cap = sel.col_idx.numel()
-        sel.col_ptr = torch.empty(self.D + 1, dtype=torch.int32, device=dev)
-        sel.csc_row = torch.empty(cap, dtype=torch.int32, device=dev)
-        sel.csc_pos = torch.empty(cap, dtype=torch.int32, device=dev)
+        if part != 2:
+            sel._csc_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            cap = sel.col_idx.numel()
+            sel.col_ptr = torch.empty(self.D + 1, dtype=torch.int32, device=dev)
+            sel.csc_row = torch.empty(cap, dtype=torch.int32, device=dev)
+            sel.csc_pos = torch.empty(cap, dtype=torch.int32, device=dev)
+        ws = sel._csc_ws
         if dead_cnt is not None:
             _need(dead_cnt, "num_batches_not_active", torch.float32, (self.D,))
-        check(self.lib.mtc_build_csc(C.byref(d), _p(sel.row_ptr), _p(sel.col_idx), _p(ws), ws_bytes, _p(sel.col_ptr),
-                                     _p(sel.csc_row), _p(sel.csc_pos), _p(dead_cnt), _stream()), "mtc_build_csc")
+        if part == 0:
+            check(self.lib.mtc_build_csc(C.byref(d), _p(sel.row_ptr), _p(sel.col_idx), _p(ws), ws_bytes, _p(sel.col_ptr),
+                                         _p(sel.csc_row), _p(sel.csc_pos), _p(dead_cnt), _stream()), "mtc_build_csc")
+        else:
+            check(self.lib.mtc_build_csc_part(C.byref(d), _p(sel.row_ptr), _p(sel.col_idx), _p(ws), ws_bytes, _p(sel.col_ptr),
+                                              _p(sel.csc_row), _p(sel.csc_pos), _p(dead_cnt), int(part), _stream()),
+                  "mtc_build_csc_part")
+        if part != 1:
+            sel._csc_ws = None
 
     # ------------------------------------------------------------------ a6 / a8 / a10
     def decode(self, d, sel: Selection, W_dec, b_dec, x_target, mean, std, *, want_g: bool, want_dvals: bool,
@@ -365,13 +377,16 @@ class HotPath:
         return dst
 
     def aux_forward_dense(self, d, acts, dead_cnt, n_batches_to_dead: float, top_k_aux: int, aux_penalty: float, W_dec,
-                          x_target, x_hat, std, g, need_grad: bool, dead=None, reduce_partial=None, global_active=None):
+                          x_target, x_hat, std, g, need_grad: bool, dead=None, reduce_partial=None, global_active=None,
+                          side=None):
         """a9 in the reference's own dense form over the compacted dead set (sae.py:332-341) on libmtc's MFMA tiles
         (mtc_gemm_nt; no BLAS library): per-row top-k_aux selection -> acts_aux [B, n_pad] -> x_hat_aux = acts_aux .
         W_dec[dead] -> residual / loss / g update fused elementwise.  `dead` = aux_dead_list() made by the caller, with
         `dead.cap` = a host-side upper bound of its length (sizes the launches; the true length stays on the device).
         `reduce_partial` (sharded dictionary): called on the fp32 partial reconstruction (all-reduce).  Returns
-        (ctx dict, aux_rows[B]); g is updated in place."""
+        (ctx dict, aux_rows[B]); g is updated in place.  `side` (fused two-stream step): a second stream for the two
+        operand transposes of the backward, each of which depends on ONE forward result and is needed launches later --
+        they run beside products that leave CUs idle instead of between them."""
         dev = acts.device
         lib, s = self.lib, _stream()
         B = d.B
@@ -390,13 +405,27 @@ class HotPath:
         check(lib.mtc_aux_select_dense(C.byref(d), _p(acts), _p(dead_idx), _p(n_dead), int(top_k_aux), n_pad, _p(row_cnt),
                                        _p(row_tau), _p(row_quota), _p(acts_aux), s), "mtc_aux_select_dense")
         return self._aux_dense_tail(d, dead, acts_aux, n_pad, aux_penalty, W_dec, x_target, x_hat, std, g, need_grad,
-                                    reduce_partial, n_dead if global_active is None else global_active)
+                                    reduce_partial, n_dead if global_active is None else global_active, side=side)
 
     def _aux_dense_tail(self, d, dead, acts_aux, n_pad, aux_penalty, W_dec, x_target, x_hat, std, g, need_grad,
-                        reduce_partial, active):
+                        reduce_partial, active, side=None):
         dev, B = acts_aux.device, d.B
+        main = torch.cuda.current_stream()
+        ctx = dict(dense=True, dead=dead, n_pad=n_pad)
         # W_dec[dead]^T (rows >= n_dead meet zero activations only): gather + transpose in one pass, then the product
+        # (it stays on this stream.  Measured elsewhere: beside the dense selection, which fills the chip, it took as long
+        # as the selection; right behind the dead list on the side stream it pushed the second half of the CSC build
+        # into the selection instead -- no gain either way)
         W_deadT = self.transpose_rows(W_dec, n_pad, self.A_t, src_rows=dead.dead_idx)             # [A_t][n_pad]
+        if side is not None and need_grad:
+            # acts_aux^T (the backward's operand) beside the forward product, which leaves CUs idle
+            e_sel = torch.cuda.Event()
+            e_sel.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(e_sel)
+                ctx["acts_auxT"] = self.transpose_rows(acts_aux, B, n_pad)                         # [n_pad][B]
+                ctx["acts_auxT_event"] = torch.cuda.Event()
+                ctx["acts_auxT_event"].record(side)
         if reduce_partial is None:
             x_hat_aux = torch.empty(B, self.A_t, dtype=self.dtype, device=dev)
             self.gemm_nt(B, self.A_t, n_pad, acts_aux, n_pad, W_deadT, n_pad, x_hat_aux, self.A_t)   # fp32 accumulate, one rounding
@@ -408,9 +437,17 @@ class HotPath:
         aux_rows = torch.empty(B, dtype=torch.float32, device=dev)
         check(self.lib.mtc_aux_residual(C.byref(d), _p(x_hat_aux), _p(x_target), _p(x_hat), _p(std), float(aux_penalty), _p(g),
                                         _p(g_aux), _p(aux_rows), _p(active), _stream()), "mtc_aux_residual")
-        ctx = dict(dense=True, dead=dead, n_pad=n_pad)
         if need_grad:
             ctx.update(acts_aux=acts_aux, g_aux=g_aux, W_dec=W_dec)
+            if side is not None:
+                # g_aux^T: needed by the E_dec product only, three launches from here
+                e_res = torch.cuda.Event()
+                e_res.record(main)
+                with torch.cuda.stream(side):
+                    side.wait_event(e_res)
+                    ctx["g_auxT"] = self.transpose_rows(g_aux, B, self.A_t)                        # [A_t][B]
+                    ctx["g_auxT_event"] = torch.cuda.Event()
+                    ctx["g_auxT_event"].record(side)
         return ctx, aux_rows
 
     def aux_extra_rows(self, ctx, x_norm, g_loss=None, side=None):
@@ -431,11 +468,18 @@ class HotPath:
             with torch.cuda.stream(side):
                 side.wait_event(e_in)
                 x_normT = self.transpose_rows(x_norm, B, self.A_s)                                 # [A_s][B]
-        g_auxT = self.transpose_rows(g_aux, B, self.A_t)                                           # [A_t][B]
+        g_auxT = ctx.get("g_auxT") if g_loss is None else None       # made beside the forward (fused step: no loss scale)
+        if g_auxT is None:
+            g_auxT = self.transpose_rows(g_aux, B, self.A_t)                                       # [A_t][B]
         # d_acts^T [n_pad][B] = W_dec[dead] . g_aux^T, masked by the selection, and its row sums (b_enc elements)
         d_actsT = torch.empty(n_pad, B, dtype=self.dtype, device=dev)
         self.gemm_nt(n_pad, B, self.A_t, W_dec, self.A_t, g_aux, self.A_t, d_actsT, B, a_rows=dead.dead_idx)
-        acts_auxT = self.transpose_rows(acts_aux, B, n_pad)                                        # [n_pad][B]
+        acts_auxT = ctx.get("acts_auxT")
+        if acts_auxT is None:
+            acts_auxT = self.transpose_rows(acts_aux, B, n_pad)                                    # [n_pad][B]
+        else:
+            # one wait: both transposes were issued on the same stream, g_aux^T last
+            main.wait_event(ctx["g_auxT_event"] if ctx.get("g_auxT_event") is not None else ctx["acts_auxT_event"])
         e_b = torch.empty(n_pad, dtype=self.dtype, device=dev)
         check(self.lib.mtc_aux_mask_rowsum(self.code, n_pad, B, _p(acts_auxT), B, _p(d_actsT), B, _p(e_b), _stream()),
               "mtc_aux_mask_rowsum")

@@ -353,7 +353,7 @@ class ShardedMatryoshkaTranscoder(MatryoshkaTranscoder):
         return Selection(st, row_ptr, col_idx, vals)
 
     # ------------------------------------------------------------------ step 3: decode + losses
-    def _aux_prepare(self, hp, d, aux_active: bool, side=None) -> bool:
+    def _aux_prepare(self, hp, d, aux_active: bool, side=None, on_side: bool = False) -> bool:
         return aux_active            # the sharded aux branch runs in its row-gather form (no dead-list read-back)
 
     def _aux_may_be_active(self) -> bool:

@@ -255,22 +255,29 @@ class MatryoshkaTranscoder(nn.Module):
             torch.cuda.current_stream().wait_event(ev)
             self._csc_event = None
 
-    def _aux_prepare(self, hp, d, aux_active: bool, side=None) -> bool:
+    def _aux_prepare(self, hp, d, aux_active: bool, side=None, on_side: bool = False) -> bool:
         """Dense aux form: build the dead list (and read its length back) now, before the decode launch, so that the
         host has a long kernel to queue the aux launches behind.  An empty list switches the branch off.
-        side: the stream the CSC build (which updates the counters) was issued on -- with a bound carried from the
-        previous forward nothing of the list is needed on the host, so the list is made there, behind the build and
-        underneath the decode launch; the aux branch joins it (self._dead_event) when it first reads the list."""
+        side: the stream the CSC build (which updates the counters) is being issued on -- with a bound carried from the
+        previous forward nothing of the list is needed on the host, so the list is made there (on_side: the caller is
+        already inside that stream's context, between the two parts of the build); the aux branch joins it
+        (self._dead_event) when it first reads the list."""
         self._aux_dead = None
         self._dead_event = None
         bound, self._aux_bound = self._aux_bound, None
         if not aux_active or self.config.get("aux_mode", "gemm") != "gemm":
             return aux_active
         if side is not None and bound:
-            with torch.cuda.stream(side):
-                dl = hp.aux_dead_list(d, self._cnt, float(self.config["n_batches_to_dead"]))
+            def make():
+                dl_ = hp.aux_dead_list(d, self._cnt, float(self.config["n_batches_to_dead"]))
                 self._dead_event = torch.cuda.Event()
                 self._dead_event.record(side)
+                return dl_
+            if on_side:
+                dl = make()
+            else:
+                with torch.cuda.stream(side):
+                    dl = make()
             dl.cap = bound
             self._aux_dead = dl
             return True
@@ -307,25 +314,33 @@ class MatryoshkaTranscoder(nn.Module):
         side = getattr(self, "_side_stream", None)
         self._csc_event = None
         self._two_streams = side is not None and getattr(self, "_defer_dvals", False) and B * hp.D >= self._OVERLAP_MIN_ELEMS
+        self._dead_check_in -= 1
+        # steady aux-active state on two streams: the previous list's bound sizes this forward's launches, so neither the
+        # check nor the list needs the host -- both stay on the side stream, under the decode launch.  The list goes
+        # BETWEEN the two parts of the CSC build (the counters are final after part 1): the chain is starved by the decode
+        # launch and ends with it, and the aux branch, first thing after the decode, waits for the list, not for the index
+        lagged = (self._two_streams and self._dead_check_in <= 0 and bool(self._aux_bound)
+                  and cfg.get("aux_mode", "gemm") == "gemm")
         if self._two_streams:
             main = torch.cuda.current_stream()
             e_sel = torch.cuda.Event()
             e_sel.record(main)
             with torch.cuda.stream(side):                            # workspace / outputs come from the side stream's pool
                 side.wait_event(e_sel)
-                hp.build_csc(d, sel, self._cnt)
+                if lagged:
+                    hp.build_csc(d, sel, self._cnt, part=1)
+                    aux_active = self._aux_prepare(hp, d, True, side, on_side=True)
+                    hp.build_csc(d, sel, self._cnt, part=2)
+                else:
+                    hp.build_csc(d, sel, self._cnt)
                 self._csc_event = torch.cuda.Event()
                 self._csc_event.record(side)
         else:
             hp.build_csc(d, sel, self._cnt)
-        self._dead_check_in -= 1
-        # steady aux-active state on two streams: the previous list's bound sizes this forward's launches, so neither the
-        # check nor the list needs the host -- both stay on the side stream, behind the CSC build, under the decode launch
-        lagged = (self._two_streams and self._dead_check_in <= 0 and bool(self._aux_bound)
-                  and cfg.get("aux_mode", "gemm") == "gemm")
-        if self._dead_check_in <= 0 and not lagged:
-            self._join_csc()                                         # the dead-feature check below reads the counters
-        aux_active = self._aux_prepare(hp, d, self._aux_may_be_active(), side if lagged else None)
+        if not lagged:
+            if self._dead_check_in <= 0:
+                self._join_csc()                                     # the dead-feature check below reads the counters
+            aux_active = self._aux_prepare(hp, d, self._aux_may_be_active(), None)
         x_hat, g, d_vals, row_stats, scalars, aux = self._decode_and_losses(
             hp, d, sel, acts, W_dec.contiguous(), b_dec.contiguous(), x_target, mean, std, need_grad, aux_active)
         from .engine import ForwardResult
@@ -384,7 +399,8 @@ class MatryoshkaTranscoder(nn.Module):
             # the reference's own dense form over the dead set, on MFMA (cheaper than k_aux row gathers per batch row)
             return hp.aux_forward_dense(d, acts, self._cnt, float(cfg["n_batches_to_dead"]), int(cfg["top_k_aux"]),
                                         float(cfg["aux_penalty"]), W_dec, x_target, x_hat, std, g, need_grad,
-                                        dead=getattr(self, "_aux_dead", None))
+                                        dead=getattr(self, "_aux_dead", None),
+                                        side=self._side_stream if getattr(self, "_two_streams", False) else None)
         asel, g_aux, aux_rows, d_aux = hp.aux_forward(
             d, acts, self._cnt, float(cfg["n_batches_to_dead"]), int(cfg["top_k_aux"]),
             float(cfg["aux_penalty"]), W_dec, x_target, x_hat, std, g, need_grad)

@@ -316,6 +316,29 @@ def test_dense_features_long_csc_segments(gpu_lib):
     assert int((cp[1:] - cp[:-1]).max()) == 320
 
 
+def test_build_csc_in_two_parts_equals_one_call(gpu_lib):
+    """mtc_build_csc_part 1 + 2 (the aux-active step puts the dead list between them) = mtc_build_csc: same index, same
+    counters, and the counters are already final after part 1."""
+    from matryoshka_transcoder_amd.engine import HotPath
+    torch.manual_seed(3)
+    B, D, k = 96, 2048, 12
+    hp = HotPath(64, 64, [D], torch.float32, False)
+    d = hp.desc(B)
+    acts = torch.relu(torch.randn(B, D, device="cuda"))
+    cnt0 = torch.randint(0, 5, (D,), device="cuda").float()
+    sel_a = hp.select_topk(d, acts, k * B)
+    sel_b = hp.select_topk(d, acts, k * B)
+    cnt_a, cnt_b = cnt0.clone(), cnt0.clone()
+    hp.build_csc(d, sel_a, cnt_a)
+    hp.build_csc(d, sel_b, cnt_b, part=1)
+    torch.cuda.synchronize()
+    assert torch.equal(cnt_a, cnt_b) and torch.equal(sel_a.col_ptr, sel_b.col_ptr)
+    hp.build_csc(d, sel_b, cnt_b, part=2)
+    torch.cuda.synchronize()
+    assert torch.equal(cnt_a, cnt_b)
+    assert torch.equal(sel_a.csc_row, sel_b.csc_row) and torch.equal(sel_a.csc_pos, sel_b.csc_pos)
+
+
 # ------------------------------------------------------------------ carried lower bound of tau (training loop select)
 def _sel_tuple(sel, nnz):
     return (sel.state.clone(), sel.row_ptr.clone(), sel.col_idx[:nnz].clone(), sel.vals[:nnz].clone())
