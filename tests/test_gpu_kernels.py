@@ -408,6 +408,37 @@ def test_select_carry_is_identical_to_full_select(dt, gpu_lib):
     assert carry[0].item() == 0
 
 
+@pytest.mark.parametrize("B,D,k,iters", [(256, 4096, 16, 120), (4096, 36864, 96, 12)])
+def test_select_carry_fallback_stress(B, D, k, iters, gpu_lib):
+    """The fallback of the bf16 carried-bound select hands its per-row counts from every workgroup to the one whose
+    ticket comes last (agent-scope release / acquire inside one launch).  Random rescaling of the batch between calls
+    makes the bound fail in both directions again and again -- too few candidates, tau beyond the window, and in between
+    calls the window serves -- at a small shape and at config #2's (256 workgroups spread over all XCDs); every call must
+    equal the full select bit for bit."""
+    from matryoshka_transcoder_amd.engine import HotPath
+    g = torch.Generator("cpu").manual_seed(B + iters)
+    hp = HotPath(64, 64, [D], torch.bfloat16, False)
+    d = hp.desc(B)
+    carry = hp.carry_state(torch.device("cuda:0"))
+    carry.zero_()
+    base = torch.relu(torch.randn(B, D, device="cuda"))
+    scales = (torch.rand(iters, generator=g) * 1.5 + 0.5).tolist()
+    for i in range(iters):
+        if i % 3 == 2:
+            scales[i] = scales[i - 1] * 1.01             # a small move: served by the window
+    for i, sc in enumerate(scales):
+        acts = (base * sc).to(torch.bfloat16)
+        full = hp.select_topk(d, acts, k * B)
+        car = hp.select_topk(d, acts, k * B, carry=True)
+        torch.cuda.synchronize()
+        nnz = int(full.row_ptr[-1])
+        assert nnz == k * B
+        for a, b, name in zip(_sel_tuple(car, nnz), _sel_tuple(full, nnz), ("state", "row_ptr", "col_idx", "vals")):
+            assert torch.equal(a[:8] if name == "state" else a, b[:8] if name == "state" else b), (i, sc, name)
+    served, fell = int(carry[4]), int(carry[5])
+    assert served + fell == iters and served >= iters // 4 and fell >= iters // 4, (served, fell)
+
+
 @pytest.mark.parametrize("B", [1000, 4096, 4104])
 def test_select_carry_window_tail_row_counts(B, gpu_lib):
     """bf16 fast path at batch sizes on both sides of the register-resident tail's limit (4 rows per thread): B = 4104
