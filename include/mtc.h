@@ -144,7 +144,11 @@ int mtc_select_global_topk(const mtc_desc* d, const void* acts, uint32_t k_total
  * >= bound into a compact [B][min(D,1024)] matrix and the exact select runs on that; if the bound
  * turns out wrong (too few candidates, or a row with more than fit) the full-size passes run
  * instead.  Both sets of launches are enqueued and predicated on a device flag: no read-back.
- * carry[4] / carry[5] count the calls served by the compact / full path. */
+ * bf16: a key has 16 bits, so the candidate pass also counts each row's candidates by their distance
+ * from the bound in ulps (32 bins) and ONE single-workgroup launch derives tau, the tie quota, the
+ * CSR offsets, the next bound (and the threshold EMA, below) from those counts; that form also
+ * needs tau within 30 ulps of the bound, i.e. a rise of at most 22 ulps in one step.
+ * carry[4] / carry[5] count the calls served by the carried bound / by the full-size passes. */
 size_t mtc_select_carry_workspace_bytes(const mtc_desc* d);
 int mtc_select_global_topk_carry(const mtc_desc* d, const void* acts, uint32_t k_total,
                                  void* workspace, size_t workspace_bytes, uint32_t* carry,
