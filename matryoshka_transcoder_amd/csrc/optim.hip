@@ -291,6 +291,9 @@ __global__ __launch_bounds__(256, (DT == MTC_BF16 ? (NC <= 5 ? MTC_FUSED_WAVES :
 // row-wide reduction (no projection), so slices are independent; the bias element rides with slice 0.
 // Coefficients d a_bj are read in CSC order (coef[e], written that way by the decoder launch).  Same arithmetic per
 // element as the row kernel (entries accumulated in ascending row order, one rounding of the gradient, op-by-op Adam).
+#ifndef MTC_SLICED_WAVES
+#define MTC_SLICED_WAVES 8               // waves per SIMD the register budget is set for
+#endif
 #ifndef MTC_SLICED_U
 #define MTC_SLICED_U 2
 #endif
@@ -298,7 +301,7 @@ __global__ __launch_bounds__(256, (DT == MTC_BF16 ? (NC <= 5 ? MTC_FUSED_WAVES :
 //   to run before its update pass -- gather, gradient slice, and the slice's share of the two row-wide sums the unit-norm
 //   projection needs (|w|^2 and grad . w), written to scratch [D][slices][2]; no moments, nothing updated.
 template <int DT, int LPF, int EXTRA, int PASS_A = 0>
-__global__ __launch_bounds__(256, 8) void fused_enc_sliced_kernel(
+__global__ __launch_bounds__(256, MTC_SLICED_WAVES) void fused_enc_sliced_kernel(
     int D, int A, int units_per_slice, int total_units, const int32_t* __restrict__ col_ptr,
     const int32_t* __restrict__ csc_row, const float* __restrict__ coef, const void* __restrict__ src,
     const float* __restrict__ scale_p, void* __restrict__ W, void* __restrict__ m, void* __restrict__ v,

@@ -11,7 +11,7 @@ rows = list(csv.DictReader(open("gpurun_out/r03/pmc_cand/c_counter_collection.cs
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
     n = r["Kernel_Name"]
-    if "select_" in n or "decode_fwd" in n:
+    if "select_" in n or "decode_fwd" in n or "fused_" in n or "encode_bf16" in n:
         acc[n[:50]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for n, c in acc.items():
     med = {k: sorted(v)[len(v)//2] for k, v in c.items()}
