@@ -332,6 +332,9 @@ __global__ __launch_bounds__(256) void aux_dense_fill_kernel(const void* __restr
 // radix levels on the LDS copy, resolves the tie quota in dead-list order and writes the dense row with 8-byte stores.
 // Same threshold / quota / selection as the two kernels above (tests compare them bit for bit).
 //   LDS: hist 16 KB + keys n_pad * sizeof(T) (dynamic)
+#ifndef MTC_AUX_GU
+#define MTC_AUX_GU 4
+#endif
 template <int DT>
 __global__ __launch_bounds__(256) void aux_select_dense_kernel(const void* __restrict__ acts, int D, int n_pad,
                                                                const int32_t* __restrict__ dead_idx,
@@ -341,7 +344,9 @@ __global__ __launch_bounds__(256) void aux_select_dense_kernel(const void* __res
     typedef typename DType<DT>::T T;
     constexpr int EPD = 4 / (int)sizeof(T);                  // elements per dword
     extern __shared__ __align__(16) uint32_t kw[];           // [n_pad / EPD] raw bits of the row's dead columns (0 beyond n_dead)
-    __shared__ uint32_t hist[4096];
+    // 4096 bins as packed 16-bit pairs (a row holds <= 20 480 entries here: the one-pass form needs the row in 40 KB of LDS),
+    // which brings the workgroup under 20 KB: 8 workgroups per CU instead of 5 hide each other's selection phases
+    __shared__ uint32_t hist[2048];
     __shared__ uint32_t wtot[4];
     __shared__ uint32_t s_bin, s_above, s_h, s_cut;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -360,14 +365,15 @@ __global__ __launch_bounds__(256) void aux_select_dense_kernel(const void* __res
         if constexpr (DT == MTC_BF16) return ((word >> (16 * e)) & 0xffffu) << 16;
         else return word;
     };
-    for (int i = t; i < 4096; i += 256) hist[i] = 0;
+    for (int i = t; i < 2048; i += 256) hist[i] = 0;
     if (t == 0) { s_bin = 0xffffffffu; s_above = 0; s_h = 0; s_cut = 0xffffffffu; }
     __syncthreads();
-    // ---- gather the row's dead columns (4 dwords per thread in flight), level-0 histogram on the way
-    for (int w0 = t; w0 < nw; w0 += 1024) {
-        int col[4][EPD];
+    constexpr int GU = MTC_AUX_GU;
+    // ---- gather the row's dead columns (MTC_AUX_GU dwords per thread in flight: the pass is a chain of index -> value round trips), level-0 histogram on the way
+    for (int w0 = t; w0 < nw; w0 += 256 * GU) {
+        int col[GU][EPD];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < GU; ++u) {
             const int w = w0 + 256 * u;
 #pragma unroll
             for (int e = 0; e < EPD; ++e) col[u][e] = -1;
@@ -381,9 +387,9 @@ __global__ __launch_bounds__(256) void aux_select_dense_kernel(const void* __res
                 }
             }
         }
-        uint32_t word[4];
+        uint32_t word[GU];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < GU; ++u) {
             if constexpr (EPD == 2) {
                 const uint32_t lo = col[u][0] >= 0 ? (uint32_t)a[col[u][0]] : 0u;
                 const uint32_t hi = col[u][1] >= 0 ? (uint32_t)a[col[u][1]] : 0u;
@@ -393,14 +399,14 @@ __global__ __launch_bounds__(256) void aux_select_dense_kernel(const void* __res
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < GU; ++u) {
             const int w = w0 + 256 * u;
             if (w < nw) {
                 kw[w] = word[u];
 #pragma unroll
                 for (int e = 0; e < EPD; ++e) {
                     const uint32_t k = key_bits(word[u], e);
-                    if (k != 0 && k <= 0x7f800000u) atomicAdd(&hist[(k >> 19) & 0xfffu], 1u);
+                    if (k != 0 && k <= 0x7f800000u) { const uint32_t b = (k >> 19) & 0xfffu; atomicAdd(&hist[b >> 1], (b & 1u) ? 0x10000u : 1u); }
                 }
             }
         }
@@ -415,7 +421,7 @@ __global__ __launch_bounds__(256) void aux_select_dense_kernel(const void* __res
         const uint32_t fm = level == 2 ? 0x7fu : 0xfffu;
         const uint32_t pm = level == 0 ? 0u : (level == 1 ? 0xfff80000u : 0xffffff80u);
         if (level > 0) {
-            for (int i = t; i < 4096; i += 256) hist[i] = 0;
+            for (int i = t; i < 2048; i += 256) hist[i] = 0;
             if (t == 0) s_bin = 0xffffffffu;
             __syncthreads();
             for (int w = t; w < nwd; w += 256) {
@@ -423,7 +429,10 @@ __global__ __launch_bounds__(256) void aux_select_dense_kernel(const void* __res
 #pragma unroll
                 for (int e = 0; e < EPD; ++e) {
                     const uint32_t k = key_bits(word, e);
-                    if (k != 0 && k <= 0x7f800000u && ((k ^ prefix) & pm) == 0) atomicAdd(&hist[(k >> sh) & fm], 1u);
+                    if (k != 0 && k <= 0x7f800000u && ((k ^ prefix) & pm) == 0) {
+                        const uint32_t b = (k >> sh) & fm;
+                        atomicAdd(&hist[b >> 1], (b & 1u) ? 0x10000u : 1u);
+                    }
                 }
             }
             __syncthreads();
@@ -431,7 +440,11 @@ __global__ __launch_bounds__(256) void aux_select_dense_kernel(const void* __res
         // thread t owns bins [16t, 16t+15]; suffix sums over the threads: in the wave by shuffles, across waves through LDS
         uint32_t h[16], mine = 0;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { h[i] = hist[16 * t + i]; mine += h[i]; }
+        for (int i = 0; i < 16; ++i) {
+            const uint32_t pair = hist[8 * t + (i >> 1)];
+            h[i] = (i & 1) ? pair >> 16 : pair & 0xffffu;
+            mine += h[i];
+        }
         uint32_t suf = mine;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
