@@ -272,7 +272,9 @@ def main():
                 # card exchange through gloo (device tensors staged through the host, sharded._Comm)
                 dist.init_process_group("gloo")
             else:
-                dist.init_process_group("nccl", device_id=torch.device(device))
+                # (a collective that never completes aborts the run after 5 minutes instead of the default 10)
+                import datetime
+                dist.init_process_group("nccl", device_id=torch.device(device), timeout=datetime.timedelta(seconds=300))
             dist.barrier()
             torch.cuda.synchronize()
             collective_backend = dist.get_backend()
