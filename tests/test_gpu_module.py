@@ -252,6 +252,50 @@ def test_two_stream_step_is_bit_identical(name, gpu_lib):
     assert torch.equal(ma.num_batches_not_active, mb.num_batches_not_active)
 
 
+def test_two_stream_aux_step_is_bit_identical_at_config2_shapes(gpu_lib):
+    """The same at the shapes where the second stream is actually used (config #2: B 4096, D 36864, A 2304, bf16) with the
+    auxiliary loss active over ~5 000 dead features: CSC build in two halves with the dead list between them, operand
+    transposes and the E_enc product on the side stream beside products that leave CUs idle, b_dec update beside the
+    gradient launches -- against the one-stream step, eight steps, every output and every parameter bit for bit (a
+    missing event shows up as a difference: the schedules overlap different launches)."""
+    from matryoshka_transcoder_amd.training import FusedAdam
+    from matryoshka_transcoder_amd.transcoder import MatryoshkaTranscoder
+    A, D, B = 2304, 36864, 4096
+    cfg = dict(seed=49, prefix_sizes=[2304, 6912, 16128, 36864], act_size=A, dict_size=D, top_k=96, top_k_aux=512,
+               aux_penalty=1 / 32, n_batches_to_dead=20, l1_coeff=0.0, dtype=torch.bfloat16, device=DEV,
+               input_unit_norm=False, lr=3e-4, beta1=0.9, beta2=0.99)
+    ma = MatryoshkaTranscoder(cfg)
+    mb = MatryoshkaTranscoder(cfg)
+    mb.load_state_dict(ma.state_dict())
+    mb._overlap_ok = False
+    forced = torch.arange(5, D, 7, device=DEV)
+    for m in (ma, mb):
+        with torch.no_grad():
+            m.W_enc[:, forced] *= 0.01
+        cnt = m.num_batches_not_active
+        cnt[forced] = 20.0
+        m.num_batches_not_active = cnt
+    oa = FusedAdam(ma, lr=cfg["lr"], betas=(cfg["beta1"], cfg["beta2"]))
+    ob = FusedAdam(mb, lr=cfg["lr"], betas=(cfg["beta1"], cfg["beta2"]))
+    g = torch.Generator(DEV).manual_seed(7)
+    for step in range(8):
+        xs = torch.randn(B, A, generator=g, device=DEV).to(torch.bfloat16)
+        xt = torch.randn(B, A, generator=g, device=DEV).to(torch.bfloat16)
+        out_a, out_b = oa.train_step(xs, xt), ob.train_step(xs, xt)
+        for k in out_a:
+            assert torch.equal(out_a[k], out_b[k]), (step, k)
+        assert float(out_a["aux_loss"]) > 0
+    torch.cuda.synchronize()
+    assert ma._side_stream is not None and getattr(mb, "_side_stream", None) is None
+    assert ma._last_res.aux is not None and ma._last_res.aux.get("acts_auxT") is not None      # the side-stream forms ran
+    for (n, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+        assert torch.equal(pa, pb), n
+        assert torch.equal(oa.state[pa]["exp_avg"], ob.state[pb]["exp_avg"]), n
+        assert torch.equal(oa.state[pa]["exp_avg_sq"], ob.state[pb]["exp_avg_sq"]), n
+    assert torch.equal(ma.num_batches_not_active, mb.num_batches_not_active)
+    assert torch.equal(ma.threshold, mb.threshold)
+
+
 def test_device_guard_and_device_mismatch(gpu_lib, monkeypatch):
     """libmtc launches on HIP's current device with raw pointers: every public entry point makes the parameters' GPU
     current first (free when it already is) and refuses inputs that live elsewhere (a caller whose current
